@@ -1,0 +1,205 @@
+/*
+ * pyqsm_hip.h — C-ABI of libpyqsm_hip.so, the MI355X (gfx950) implementation of
+ * pyQSM's point-cloud geometry hot path.
+ *
+ * The reference (wischmcj/pyQSM) is pure Python and has no FFI of its own; the
+ * seam it offers is a handful of Python call sites into third-party engines.
+ * Every entry point below names the reference call it stands in for
+ * (file:line relative to the reference root).  The Python wrappers in
+ * pyqsm_amd/ bind these symbols with ctypes and expose the reference's own
+ * function names and signatures on top.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; caller owns every buffer it passes in;
+ *     arrays are C-contiguous; no exceptions cross the ABI
+ *   - return 0 on success, a negative PYQSM_E* code on failure; the message is
+ *     available (per thread) from pyqsm_last_error()
+ *   - "host" entry points take host pointers and stage through HBM themselves;
+ *     "_dev" entry points take device pointers (HBM-resident input/output,
+ *     obtained from pyqsm_dev_malloc or any hipMalloc'd allocation) and are
+ *     asynchronous on the library's per-device stream until pyqsm_sync()
+ *   - the library owns one HIP stream and one scratch arena per device
+ */
+#ifndef PYQSM_HIP_H
+#define PYQSM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PYQSM_OK 0
+#define PYQSM_EINVAL (-1)   /* bad argument (null pointer, negative size, ...)   */
+#define PYQSM_EHIP (-2)     /* a HIP runtime call failed                         */
+#define PYQSM_ENODEV (-3)   /* no usable GPU / device index out of range         */
+#define PYQSM_ERANGE (-4)   /* input outside what the kernels are built for      */
+#define PYQSM_ENOMEM (-5)   /* device or host allocation failed                  */
+#define PYQSM_ENOCONV (-6)  /* iterative solve hit max_it before reaching rtol   */
+
+#define PYQSM_MISS_PRIM 0xFFFFFFFFu /* primitive id reported for a ray that hits nothing */
+
+/* ---- library / device management ------------------------------------- */
+
+/* Number of visible GPUs (0 when none); never fails. */
+int pyqsm_device_count(void);
+/* Create the per-device context (stream + arena). Idempotent. */
+int pyqsm_init(int device);
+/* Destroy every context created by pyqsm_init. */
+int pyqsm_shutdown(void);
+/* Message of the last failure on the calling thread ("" when none). */
+const char* pyqsm_last_error(void);
+/* "pyqsm_hip <version> gfx950" */
+const char* pyqsm_version(void);
+/* Block until the library stream of `device` has drained. */
+int pyqsm_sync(int device);
+/* The library's hipStream_t for `device`, as an opaque pointer (for callers
+ * that order their own work against it). */
+void* pyqsm_stream(int device);
+
+/* HBM buffers for the _dev entry points. */
+int pyqsm_dev_malloc(int device, size_t bytes, void** out);
+int pyqsm_dev_free(int device, void* p);
+int pyqsm_h2d(int device, void* dst_dev, const void* src_host, size_t bytes);
+int pyqsm_d2h(int device, void* dst_host, const void* src_dev, size_t bytes);
+/* Release memory returned through an `**` out-parameter of a host entry point. */
+void pyqsm_free(void* p);
+
+/* HIP-event timers around named kernel groups on the library stream.
+ * Disabled by default (zero overhead); bench.py switches them on to measure
+ * the dominant kernel's average launch duration live. */
+int pyqsm_prof_enable(int device, int on);
+int pyqsm_prof_reset(int device);
+/* Sum of elapsed ms and number of launches recorded under `name`
+ * since the last reset. Synchronises the stream. */
+int pyqsm_prof_get(int device, const char* name, double* total_ms, int64_t* launches);
+
+/* ---- ray x triangle sweep -------------------------------------------- */
+/*
+ * Closest-hit ray casting against a triangle soup, brute force (no BVH).
+ * Stands in for open3d.t.geometry.RaycastingScene.add_triangles + cast_rays as
+ * called at pyQSM/viz/ray_casting.py:275-279 (also :218-225, :316-319).
+ *   verts  f32 [V,3]     tris  i32 [T,3] (indices into verts)
+ *   rays   f32 [R,6] = (ox,oy,oz,dx,dy,dz); d need not be unit, t is in units of |d|
+ *   t_hit  f32 [R]  (+inf on miss)      prim_id u32 [R] (PYQSM_MISS_PRIM on miss)
+ *   uv     f32 [R,2] or NULL; hit = (1-u-v)*v0 + u*v1 + v*v2 (ray_casting.py:172-180)
+ *   Ties in t go to the lowest triangle index. A hit needs t > 0.
+ */
+int pyqsm_cast_rays(const float* verts, int64_t V, const int32_t* tris, int64_t T,
+                    const float* rays, int64_t R,
+                    float* t_hit, uint32_t* prim_id, float* uv, int32_t device);
+
+/* Device-resident form. `tri9` is the expanded mesh produced by
+ * pyqsm_expand_tris_dev: f32 [T,12] = (v0.xyz, e1.xyz, e2.xyz, 0,0,0). */
+int pyqsm_expand_tris_dev(const float* verts_dev, int64_t V, const int32_t* tris_dev,
+                          int64_t T, float* tri12_dev, int32_t device);
+int pyqsm_cast_rays_dev(const float* tri12_dev, int64_t T, const float* rays_dev, int64_t R,
+                        float* t_hit_dev, uint32_t* prim_id_dev, float* uv_dev,
+                        int32_t device);
+
+/* All intersections (RaycastingScene.list_intersections, ray_casting.py:168) and
+ * crossing counts (compute_occupancy, ray_casting.py:65-69 = odd count).
+ *   counts i32 [R] = number of triangles each ray crosses with t > 0.
+ *   If hits_cap > 0: up to hits_cap records (ray_id u32, prim_id u32, t f32, u f32, v f32)
+ *   are written, ordered by ray id then triangle id; *n_hits = total found. */
+int pyqsm_list_intersections(const float* verts, int64_t V, const int32_t* tris, int64_t T,
+                             const float* rays, int64_t R, int32_t* counts,
+                             uint32_t* ray_ids, uint32_t* prim_ids, float* t, float* uv,
+                             int64_t hits_cap, int64_t* n_hits, int32_t device);
+
+/* ---- eps-neighbourhood clustering (DBSCAN) ---------------------------- */
+/*
+ * Stands in for sklearn.cluster.DBSCAN(eps, min_samples).fit(points) at
+ * pyQSM/math_utils/fit.py:223 and open3d PointCloud.cluster_dbscan at
+ * pyQSM/geometry/point_cloud_processing.py:185,209.
+ *   xyz f64 [n,3]; labels i64 [n] (-1 = noise); is_core u8 [n] (may be NULL)
+ * Semantics (bit-exact with scikit-learn): core <=> #{j : d2(i,j) <= eps*eps} >=
+ * min_pts counting i itself, d2 = ((dx*dx + dy*dy) + dz*dz) in fp64 without
+ * contraction; clusters = connected components of the core-core eps graph,
+ * numbered by ascending smallest core index; a border point takes the smallest
+ * cluster label among its core neighbours.
+ */
+int pyqsm_dbscan(const double* xyz, int64_t n, double eps, int32_t min_pts,
+                 int64_t* labels, uint8_t* is_core, int32_t device);
+int pyqsm_dbscan_dev(const double* xyz_dev, int64_t n, double eps, int32_t min_pts,
+                     int64_t* labels_dev, uint8_t* is_core_dev, int64_t* n_clusters,
+                     int32_t device);
+
+/* ---- k nearest neighbours --------------------------------------------- */
+/*
+ * Exact kNN over one cloud (query set = data set). Stands in for the neighbour
+ * search inside robust_laplacian.point_cloud_laplacian (pyQSM/geometry/
+ * skeletonize.py:253-255) and scipy cKDTree.query (pyQSM/geometry/
+ * reconstruction.py:238-240).
+ *   idx i32 [n,k], d2 f64 [n,k] (squared distance), ascending by (d2, index);
+ *   exclude_self != 0 drops the query point itself. Rows are padded with
+ *   idx = n, d2 = +inf when the cloud has fewer than k (other) points.
+ */
+int pyqsm_knn(const double* xyz, int64_t n, int32_t k, int32_t exclude_self,
+              int32_t* idx, double* d2, int32_t device);
+int pyqsm_knn_dev(const double* xyz_dev, int64_t n, int32_t k, int32_t exclude_self,
+                  int32_t* idx_dev, double* d2_dev, int32_t device);
+
+/* ---- RANSAC circle / cylinder ------------------------------------------ */
+/*
+ * Stands in for pyransac3d.Circle().fit / Cylinder().fit as called at
+ * pyQSM/math_utils/fit.py:277-283. The caller supplies the 3-point samples
+ * (the reference draws them from Python's unseeded `random`), one row per
+ * hypothesis, so that runs are reproducible.
+ *   pts f64 [n,3]; triples i64 [H,3]; shape 0 = circle, 1 = cylinder
+ *   center[3], axis[3], *radius: model of the winning hypothesis (first
+ *   hypothesis with a strictly larger inlier count wins)
+ *   inliers i64 [n] capacity, ascending; *n_inliers = count; *best = winning row
+ *   (-1 and n_inliers = 0 when no hypothesis has an inlier).
+ */
+int pyqsm_ransac(const double* pts, int64_t n, const int64_t* triples, int64_t H,
+                 int32_t shape, double thresh, double center[3], double axis[3],
+                 double* radius, int64_t* inliers, int64_t* n_inliers, int64_t* best,
+                 int32_t device);
+/* The two halves separately: models f64 [H,8] = (cx,cy,cz, ax,ay,az, r, valid). */
+int pyqsm_ransac_models(const double* pts, int64_t n, const int64_t* triples, int64_t H,
+                        double* models, int32_t device);
+int pyqsm_ransac_count(const double* pts, int64_t n, const double* models, int64_t H,
+                       int32_t shape, double thresh, int32_t* counts, int32_t device);
+
+/* ---- Laplacian-contraction solve --------------------------------------- */
+/*
+ * One contraction solve of pyQSM/geometry/skeletonize.py:148-180
+ * (least_squares_sparse): minimise |W_L L x|^2 + |W_H (x - p)|^2 per coordinate,
+ * i.e. (L' W_L^2 L + W_H^2) x = W_H^2 p, by a preconditioned conjugate
+ * gradient over 3 right-hand sides that never forms L'L.
+ *   L as CSR (indptr i32 [n+1], indices i32 [nnz], vals f64 [nnz]);
+ *   wl, wh, f64 [n]; pts f64 [n,3] (also the start vector); out f64 [n,3]
+ *   stops when |r|/|b| <= rtol for every coordinate or after max_it iterations
+ *   (then returns PYQSM_ENOCONV with the best iterate in `out`).
+ */
+int pyqsm_lbc_solve(const int32_t* indptr, const int32_t* indices, const double* vals,
+                    int64_t n, const double* wl, const double* wh, const double* pts,
+                    double rtol, int32_t max_it, double* out, int32_t* iters,
+                    double* resid, int32_t device);
+/* y = L x for 3 columns at once (x, y f64 [n,3]); the SpMV the solve is built on. */
+int pyqsm_spmv3(const int32_t* indptr, const int32_t* indices, const double* vals,
+                int64_t n, const double* x, double* y, int32_t device);
+/* In-place clamp of every coordinate into [lo, hi] (skeletonize.py:291-296). */
+int pyqsm_clamp(double* pts, int64_t n, const double lo[3], const double hi[3],
+                int32_t device);
+
+/* ---- point-cloud Laplacian ---------------------------------------------- */
+/*
+ * Stands in for robust_laplacian.point_cloud_laplacian(pts, mollify_factor,
+ * n_neighbors) at pyQSM/geometry/skeletonize.py:253-255,341-343: kNN -> PCA
+ * normal -> tangent-plane projection -> local Delaunay fan per point -> union
+ * of fan triangles -> mollified cotangent Laplacian and lumped mass, both / 3.
+ *   On success the indptr / indices / vals out-parameters hold a CSR matrix
+ *   (symmetric, zero row sums) owned by the library: release each with
+ *   pyqsm_free. mass f64 [n].
+ */
+int pyqsm_pc_laplacian(const double* xyz, int64_t n, int32_t k, double moll,
+                       int64_t* nnz, int32_t** indptr, int32_t** indices, double** vals,
+                       double* mass, int32_t device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYQSM_HIP_H */

@@ -1,0 +1,425 @@
+/*
+ * pyqsm_oracle.c — CPU restatement of the engines pyQSM's hot path calls.
+ *
+ * TEST INFRASTRUCTURE ONLY. Nothing under pyqsm_amd/ may import, link or call
+ * this file; it exists so that tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg can check (and time) the HIP path against an independent
+ * CPU statement of the same algorithm.
+ *
+ * Parity status (see DESIGN.md "Oracle"):
+ *   orc_dbscan     follows scikit-learn's DBSCAN as called at
+ *                  pyQSM/math_utils/fit.py:223 (radius neighbourhoods, then the
+ *                  sequential expansion of sklearn/cluster/_dbscan_inner.pyx);
+ *                  PINNED: tests/golden/dbscan_*.npz were produced by
+ *                  scikit-learn 1.7.2 itself (tests/golden/make_golden.py).
+ *   orc_knn        follows scipy.spatial.cKDTree.query as called at
+ *                  pyQSM/geometry/reconstruction.py:238-240; PINNED the same way.
+ *   orc_cast_rays  Moller-Trumbore closest hit standing in for Open3D/Embree
+ *                  (pyQSM/viz/ray_casting.py:275-279). Open3D is not installable
+ *                  here: PARITY UNPINNED against Embree; pinned only by analytic
+ *                  known answers in tests/.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------ */
+/* uniform grid over a cloud (acceleration only; results do not depend on it) */
+
+typedef struct {
+  double min[3];
+  double inv_cell;
+  int64_t dim[3];
+  int64_t ncell;
+  int64_t* start; /* [ncell+1] */
+  int64_t* order; /* [n] point ids sorted by cell */
+} grid_t;
+
+static int64_t cell_coord(double x, double mn, double inv, int64_t dim) {
+  int64_t c = (int64_t)floor((x - mn) * inv);
+  if (c < 0) c = 0;
+  if (c >= dim) c = dim - 1;
+  return c;
+}
+
+static int grid_build(grid_t* g, const double* xyz, int64_t n, double cell) {
+  double mx[3];
+  for (int a = 0; a < 3; ++a) {
+    g->min[a] = INFINITY;
+    mx[a] = -INFINITY;
+  }
+  for (int64_t i = 0; i < n; ++i)
+    for (int a = 0; a < 3; ++a) {
+      double v = xyz[3 * i + a];
+      if (v < g->min[a]) g->min[a] = v;
+      if (v > mx[a]) mx[a] = v;
+    }
+  /* grow the cell until the dense grid is affordable */
+  for (;;) {
+    g->inv_cell = 1.0 / cell;
+    double tot = 1.0;
+    for (int a = 0; a < 3; ++a) {
+      double d = floor((mx[a] - g->min[a]) * g->inv_cell) + 1.0;
+      if (!(d >= 1.0)) d = 1.0;
+      g->dim[a] = (int64_t)d;
+      tot *= d;
+    }
+    if (tot <= 2.0e8) break;
+    cell *= 2.0;
+  }
+  g->ncell = g->dim[0] * g->dim[1] * g->dim[2];
+  g->start = (int64_t*)calloc((size_t)g->ncell + 1, sizeof(int64_t));
+  g->order = (int64_t*)malloc((size_t)(n > 0 ? n : 1) * sizeof(int64_t));
+  int64_t* cid = (int64_t*)malloc((size_t)(n > 0 ? n : 1) * sizeof(int64_t));
+  if (!g->start || !g->order || !cid) return -1;
+  for (int64_t i = 0; i < n; ++i) {
+    int64_t cx = cell_coord(xyz[3 * i], g->min[0], g->inv_cell, g->dim[0]);
+    int64_t cy = cell_coord(xyz[3 * i + 1], g->min[1], g->inv_cell, g->dim[1]);
+    int64_t cz = cell_coord(xyz[3 * i + 2], g->min[2], g->inv_cell, g->dim[2]);
+    cid[i] = (cz * g->dim[1] + cy) * g->dim[0] + cx;
+    g->start[cid[i] + 1]++;
+  }
+  for (int64_t c = 0; c < g->ncell; ++c) g->start[c + 1] += g->start[c];
+  int64_t* fill = (int64_t*)malloc((size_t)g->ncell * sizeof(int64_t));
+  if (!fill) return -1;
+  memcpy(fill, g->start, (size_t)g->ncell * sizeof(int64_t));
+  for (int64_t i = 0; i < n; ++i) g->order[fill[cid[i]]++] = i; /* ascending ids per cell */
+  free(fill);
+  free(cid);
+  return 0;
+}
+
+static void grid_free(grid_t* g) {
+  free(g->start);
+  free(g->order);
+}
+
+/* squared distance exactly as sklearn's EuclideanDistance.rdist and scipy's
+ * cKDTree accumulate it: d = 0; d += t*t for each axis in order, in double,
+ * no fused multiply-add. */
+static inline double sqdist(const double* a, const double* b) {
+  double t0 = a[0] - b[0], t1 = a[1] - b[1], t2 = a[2] - b[2];
+  double d = t0 * t0;
+  d = d + t1 * t1;
+  d = d + t2 * t2;
+  return d;
+}
+
+/* ------------------------------------------------------------------------ */
+/* DBSCAN                                                                     */
+
+/*
+ * labels i64 [n] (-1 noise), is_core u8 [n]. Returns the number of clusters or
+ * -1 on allocation failure.
+ *   step 1  neighbourhoods N(i) = { j : sqdist(i,j) <= eps*eps }, i included
+ *           (sklearn NearestNeighbors.radius_neighbors, reduced distance compare)
+ *   step 2  core(i) <=> |N(i)| >= min_pts
+ *   step 3  sklearn/cluster/_dbscan_inner.pyx: for i ascending, unlabelled core
+ *           points seed a depth-first expansion; a popped point takes the label
+ *           if it has none; only core points push their unlabelled neighbours.
+ */
+int64_t orc_dbscan(const double* xyz, int64_t n, double eps, int32_t min_pts, int64_t* labels,
+                   uint8_t* is_core) {
+  if (n == 0) return 0;
+  grid_t g;
+  /* cell a hair wider than eps so that rounding in the cell index can never
+   * separate two points that are within eps of each other by two cells */
+  if (grid_build(&g, xyz, n, eps * (1.0 + 1.0 / 1048576.0)) != 0) return -1;
+  const double r2 = eps * eps;
+  int64_t* nstart = (int64_t*)calloc((size_t)n + 1, sizeof(int64_t));
+  if (!nstart) return -1;
+  /* pass 1: counts; pass 2: fill */
+  int32_t* nbr = NULL;
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pass == 1) {
+      for (int64_t i = 0; i < n; ++i) nstart[i + 1] += nstart[i];
+      nbr = (int32_t*)malloc((size_t)(nstart[n] > 0 ? nstart[n] : 1) * sizeof(int32_t));
+      if (!nbr) return -1;
+    }
+#pragma omp parallel for schedule(dynamic, 1024)
+    for (int64_t i = 0; i < n; ++i) {
+      const double* p = xyz + 3 * i;
+      int64_t cx = cell_coord(p[0], g.min[0], g.inv_cell, g.dim[0]);
+      int64_t cy = cell_coord(p[1], g.min[1], g.inv_cell, g.dim[1]);
+      int64_t cz = cell_coord(p[2], g.min[2], g.inv_cell, g.dim[2]);
+      int64_t cnt = 0;
+      int64_t w = pass == 1 ? nstart[i] : 0;
+      for (int64_t z = cz - 1; z <= cz + 1; ++z) {
+        if (z < 0 || z >= g.dim[2]) continue;
+        for (int64_t y = cy - 1; y <= cy + 1; ++y) {
+          if (y < 0 || y >= g.dim[1]) continue;
+          int64_t x0 = cx > 0 ? cx - 1 : 0, x1 = cx + 1 < g.dim[0] ? cx + 1 : g.dim[0] - 1;
+          int64_t row = (z * g.dim[1] + y) * g.dim[0];
+          for (int64_t s = g.start[row + x0]; s < g.start[row + x1 + 1]; ++s) {
+            int64_t j = g.order[s];
+            if (sqdist(p, xyz + 3 * j) <= r2) {
+              if (pass == 1) nbr[w++] = (int32_t)j;
+              ++cnt;
+            }
+          }
+        }
+      }
+      if (pass == 0) nstart[i + 1] = cnt;
+    }
+  }
+  for (int64_t i = 0; i < n; ++i) {
+    is_core[i] = (nstart[i + 1] - nstart[i]) >= min_pts;
+    labels[i] = -1;
+  }
+  int64_t* stack = (int64_t*)malloc((size_t)(nstart[n] + n + 1) * sizeof(int64_t));
+  if (!stack) return -1;
+  int64_t label_num = 0;
+  for (int64_t s = 0; s < n; ++s) {
+    if (labels[s] != -1 || !is_core[s]) continue;
+    int64_t sp = 0, i = s;
+    for (;;) {
+      if (labels[i] == -1) {
+        labels[i] = label_num;
+        if (is_core[i])
+          for (int64_t q = nstart[i]; q < nstart[i + 1]; ++q) {
+            int64_t v = nbr[q];
+            if (labels[v] == -1) stack[sp++] = v;
+          }
+      }
+      if (sp == 0) break;
+      i = stack[--sp];
+    }
+    ++label_num;
+  }
+  free(stack);
+  free(nbr);
+  free(nstart);
+  grid_free(&g);
+  return label_num;
+}
+
+/* ------------------------------------------------------------------------ */
+/* kNN                                                                        */
+
+typedef struct {
+  double d2;
+  int32_t id;
+} cand_t;
+
+static inline int cand_less(double d2a, int32_t ia, double d2b, int32_t ib) {
+  return d2a < d2b || (d2a == d2b && ia < ib);
+}
+
+/*
+ * idx i32 [n,k], d2 f64 [n,k], ascending by (d2, index). Pads with idx = n,
+ * d2 = +inf. The search visits grid shells of growing radius until the k-th
+ * distance is provably final (<= (r*cell)^2), so the result is exact.
+ */
+int orc_knn(const double* xyz, int64_t n, int32_t k, int32_t exclude_self, int32_t* idx,
+            double* d2out) {
+  if (n == 0 || k <= 0) return 0;
+  /* aim for a handful of points per occupied cell */
+  double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int64_t i = 0; i < n; ++i)
+    for (int a = 0; a < 3; ++a) {
+      double v = xyz[3 * i + a];
+      if (v < mn[a]) mn[a] = v;
+      if (v > mx[a]) mx[a] = v;
+    }
+  double ext = 0;
+  for (int a = 0; a < 3; ++a)
+    if (mx[a] - mn[a] > ext) ext = mx[a] - mn[a];
+  if (!(ext > 0)) ext = 1.0;
+  double cell = ext / 512.0;
+  grid_t g;
+  for (int it = 0;; ++it) {
+    if (grid_build(&g, xyz, n, cell) != 0) return -1;
+    int64_t occ = 0;
+    for (int64_t c = 0; c < g.ncell; ++c) occ += g.start[c + 1] > g.start[c];
+    double per = (double)n / (double)(occ > 0 ? occ : 1);
+    if (it >= 6 || (per >= 2.0 && per <= 16.0) || (per < 2.0 && g.ncell <= 8)) break;
+    double f = per < 2.0 ? 1.6 : 0.7;
+    if (per > 16.0 && cell * 0.7 * 2048.0 < ext) break; /* do not explode the grid */
+    cell = 1.0 / g.inv_cell * f;
+    grid_free(&g);
+  }
+  cell = 1.0 / g.inv_cell;
+  int64_t maxdim = g.dim[0];
+  if (g.dim[1] > maxdim) maxdim = g.dim[1];
+  if (g.dim[2] > maxdim) maxdim = g.dim[2];
+#pragma omp parallel
+  {
+    cand_t* best = (cand_t*)malloc((size_t)k * sizeof(cand_t));
+#pragma omp for schedule(dynamic, 256)
+    for (int64_t i = 0; i < n; ++i) {
+      const double* p = xyz + 3 * i;
+      int64_t c[3];
+      for (int a = 0; a < 3; ++a) c[a] = cell_coord(p[a], g.min[a], g.inv_cell, g.dim[a]);
+      int32_t have = 0;
+      for (int64_t r = 0;; ++r) {
+        /* visit the shell at Chebyshev distance r */
+        for (int64_t z = c[2] - r; z <= c[2] + r; ++z) {
+          if (z < 0 || z >= g.dim[2]) continue;
+          for (int64_t y = c[1] - r; y <= c[1] + r; ++y) {
+            if (y < 0 || y >= g.dim[1]) continue;
+            int shell_yz = (z == c[2] - r || z == c[2] + r || y == c[1] - r || y == c[1] + r);
+            for (int64_t x = c[0] - r; x <= c[0] + r; x += (shell_yz ? 1 : (r > 0 ? 2 * r : 1))) {
+              if (x < 0 || x >= g.dim[0]) continue;
+              int64_t cc = (z * g.dim[1] + y) * g.dim[0] + x;
+              for (int64_t s = g.start[cc]; s < g.start[cc + 1]; ++s) {
+                int64_t j = g.order[s];
+                if (exclude_self && j == i) continue;
+                double d = sqdist(p, xyz + 3 * j);
+                if (have < k) {
+                  int32_t q = have++;
+                  while (q > 0 && cand_less(d, (int32_t)j, best[q - 1].d2, best[q - 1].id)) {
+                    best[q] = best[q - 1];
+                    --q;
+                  }
+                  best[q].d2 = d;
+                  best[q].id = (int32_t)j;
+                } else if (cand_less(d, (int32_t)j, best[k - 1].d2, best[k - 1].id)) {
+                  int32_t q = k - 1;
+                  while (q > 0 && cand_less(d, (int32_t)j, best[q - 1].d2, best[q - 1].id)) {
+                    best[q] = best[q - 1];
+                    --q;
+                  }
+                  best[q].d2 = d;
+                  best[q].id = (int32_t)j;
+                }
+              }
+            }
+          }
+        }
+        /* every point outside the visited cube is farther than r*cell (minus a
+         * rounding hair, hence the 0.999999) */
+        double safe = (double)r * cell * 0.999999;
+        if (have == k && best[k - 1].d2 <= safe * safe) break;
+        if (r > maxdim) break;
+      }
+      for (int32_t q = 0; q < k; ++q) {
+        idx[i * k + q] = q < have ? best[q].id : (int32_t)n;
+        d2out[i * k + q] = q < have ? best[q].d2 : INFINITY;
+      }
+    }
+    free(best);
+  }
+  grid_free(&g);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* ray x triangle                                                             */
+
+/* One ray against one triangle, the operation sequence of
+ * pyqsm_amd/csrc/raycast.hip (see its header for the contract). */
+static inline int mt(const float* o, const float* d, const float* v0, const float* e1,
+                     const float* e2, float* t, float* u, float* v) {
+  float px = __builtin_fmaf(d[1], e2[2], -(d[2] * e2[1]));
+  float py = __builtin_fmaf(d[2], e2[0], -(d[0] * e2[2]));
+  float pz = __builtin_fmaf(d[0], e2[1], -(d[1] * e2[0]));
+  float det = __builtin_fmaf(e1[0], px, __builtin_fmaf(e1[1], py, e1[2] * pz));
+  float tx = o[0] - v0[0], ty = o[1] - v0[1], tz = o[2] - v0[2];
+  float U = __builtin_fmaf(tx, px, __builtin_fmaf(ty, py, tz * pz));
+  float qx = __builtin_fmaf(ty, e1[2], -(tz * e1[1]));
+  float qy = __builtin_fmaf(tz, e1[0], -(tx * e1[2]));
+  float qz = __builtin_fmaf(tx, e1[1], -(ty * e1[0]));
+  float V = __builtin_fmaf(d[0], qx, __builtin_fmaf(d[1], qy, d[2] * qz));
+  float Tn = __builtin_fmaf(e2[0], qx, __builtin_fmaf(e2[1], qy, e2[2] * qz));
+  float W = det - (U + V);
+  int pos = det > 0.f && U >= 0.f && V >= 0.f && W >= 0.f && Tn > 0.f;
+  int neg = det < 0.f && U <= 0.f && V <= 0.f && W <= 0.f && Tn < 0.f;
+  if (!(pos || neg)) return 0;
+  *t = Tn / det;
+  *u = U / det;
+  *v = V / det;
+  return 1;
+}
+
+static float* expand_tris(const float* verts, const int32_t* tris, int64_t T) {
+  float* rec = (float*)malloc((size_t)(T > 0 ? T : 1) * 9 * sizeof(float));
+  if (!rec) return NULL;
+  for (int64_t i = 0; i < T; ++i) {
+    const float* a = verts + 3 * (int64_t)tris[3 * i];
+    const float* b = verts + 3 * (int64_t)tris[3 * i + 1];
+    const float* c = verts + 3 * (int64_t)tris[3 * i + 2];
+    for (int k = 0; k < 3; ++k) {
+      rec[9 * i + k] = a[k];
+      rec[9 * i + 3 + k] = b[k] - a[k];
+      rec[9 * i + 6 + k] = c[k] - a[k];
+    }
+  }
+  return rec;
+}
+
+/* Closest hit. t_hit +inf / prim 0xFFFFFFFF on miss; uv may be NULL. */
+int orc_cast_rays(const float* verts, int64_t V, const int32_t* tris, int64_t T,
+                  const float* rays, int64_t R, float* t_hit, uint32_t* prim, float* uv) {
+  (void)V;
+  float* rec = expand_tris(verts, tris, T);
+  if (!rec) return -1;
+#pragma omp parallel for schedule(dynamic, 64)
+  for (int64_t r = 0; r < R; ++r) {
+    const float* o = rays + 6 * r;
+    const float* d = o + 3;
+    float bt = INFINITY, bu = 0.f, bv = 0.f;
+    uint32_t bp = 0xFFFFFFFFu;
+    for (int64_t j = 0; j < T; ++j) {
+      float t, u, v;
+      if (mt(o, d, rec + 9 * j, rec + 9 * j + 3, rec + 9 * j + 6, &t, &u, &v) && t < bt) {
+        bt = t;
+        bu = u;
+        bv = v;
+        bp = (uint32_t)j;
+      }
+    }
+    t_hit[r] = bt;
+    prim[r] = bp;
+    if (uv) {
+      uv[2 * r] = bu;
+      uv[2 * r + 1] = bv;
+    }
+  }
+  free(rec);
+  return 0;
+}
+
+/* All hits with t > 0, ordered by ray then triangle. counts i32 [R]; if cap > 0
+ * the first `cap` records are written. Returns the total number of hits. */
+int64_t orc_list_intersections(const float* verts, int64_t V, const int32_t* tris, int64_t T,
+                               const float* rays, int64_t R, int32_t* counts, uint32_t* ray_ids,
+                               uint32_t* prim_ids, float* ts, float* uv, int64_t cap) {
+  (void)V;
+  float* rec = expand_tris(verts, tris, T);
+  if (!rec) return -1;
+  int64_t total = 0;
+  for (int64_t r = 0; r < R; ++r) {
+    const float* o = rays + 6 * r;
+    int32_t n = 0;
+    for (int64_t j = 0; j < T; ++j) {
+      float t, u, v;
+      if (mt(o, o + 3, rec + 9 * j, rec + 9 * j + 3, rec + 9 * j + 6, &t, &u, &v)) {
+        if (total < cap) {
+          ray_ids[total] = (uint32_t)r;
+          prim_ids[total] = (uint32_t)j;
+          ts[total] = t;
+          uv[2 * total] = u;
+          uv[2 * total + 1] = v;
+        }
+        ++total;
+        ++n;
+      }
+    }
+    counts[r] = n;
+  }
+  free(rec);
+  return total;
+}
+
+int orc_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}

@@ -1,0 +1,98 @@
+// common.hpp — per-device context (stream, scratch arena, event timers) and
+// error plumbing shared by every translation unit of libpyqsm_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/pyqsm_hip.h"
+
+namespace pyqsm {
+
+void set_error(const char* fmt, ...);
+int fail(int code, const char* fmt, ...);
+
+#define PQ_HIP(expr)                                                                   \
+  do {                                                                                 \
+    hipError_t e__ = (expr);                                                           \
+    if (e__ != hipSuccess)                                                             \
+      return ::pyqsm::fail(e__ == hipErrorOutOfMemory ? PYQSM_ENOMEM : PYQSM_EHIP,     \
+                           "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__),     \
+                           __FILE__, __LINE__);                                        \
+  } while (0)
+
+#define PQ_TRY(expr)         \
+  do {                       \
+    int r__ = (expr);        \
+    if (r__ != 0) return r__; \
+  } while (0)
+
+// Grow-only scratch memory. alloc() bumps inside the current chunk and adds a
+// chunk when it runs out; reset() folds several chunks into one of the summed
+// size so that a repeated call of the same shape allocates nothing.
+class Arena {
+ public:
+  int alloc(size_t bytes, void** out);
+  template <typename T>
+  int get(size_t count, T** out) {
+    return alloc(count * sizeof(T), reinterpret_cast<void**>(out));
+  }
+  int reset();
+  void destroy();
+
+ private:
+  struct Chunk {
+    char* base;
+    size_t size;
+    size_t used;
+  };
+  std::vector<Chunk> chunks_;
+};
+
+struct Timer {
+  double ms = 0.0;
+  int64_t launches = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+struct Ctx {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  Arena arena;
+  std::mutex mu;  // calls on one device serialise
+  bool prof = false;
+  std::map<std::string, Timer> timers;
+  std::vector<hipEvent_t> event_pool;
+  int cu_count = 256;
+};
+
+// Returns the context for `device`, creating it on first use. nullptr + error
+// message when the device does not exist.
+Ctx* ctx_for(int device);
+
+// RAII bracket: records a start/stop event pair on the stream under `name`
+// when profiling is enabled; otherwise does nothing.
+class ProfScope {
+ public:
+  ProfScope(Ctx* c, const char* name);
+  ~ProfScope();
+
+ private:
+  Ctx* c_;
+  Timer* t_ = nullptr;
+  hipEvent_t start_ = nullptr;
+};
+
+inline int ceil_div(int64_t a, int64_t b) { return static_cast<int>((a + b - 1) / b); }
+
+// Exclusive prefix sum of n int32 values, in place, on the stream (scan.hip).
+int exclusive_scan_i32(Ctx* c, int32_t* data, int64_t n);
+
+}  // namespace pyqsm

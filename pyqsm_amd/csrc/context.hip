@@ -1,0 +1,262 @@
+// context.hip — library/device management half of the C-ABI (include/pyqsm_hip.h).
+#include "common.hpp"
+
+namespace pyqsm {
+
+static thread_local char g_err[1024] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+// ---- arena ------------------------------------------------------------
+
+static constexpr size_t kAlign = 256;
+
+int Arena::alloc(size_t bytes, void** out) {
+  bytes = (bytes + kAlign - 1) / kAlign * kAlign;
+  if (bytes == 0) bytes = kAlign;
+  if (!chunks_.empty()) {
+    Chunk& c = chunks_.back();
+    if (c.used + bytes <= c.size) {
+      *out = c.base + c.used;
+      c.used += bytes;
+      return 0;
+    }
+  }
+  size_t want = bytes;
+  if (want < (size_t(64) << 20)) want = size_t(64) << 20;
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, want);
+  if (e != hipSuccess && want > bytes) {
+    want = bytes;
+    e = hipMalloc(&p, want);
+  }
+  if (e != hipSuccess)
+    return fail(PYQSM_ENOMEM, "scratch arena: hipMalloc(%zu) failed: %s", want,
+                hipGetErrorString(e));
+  chunks_.push_back({static_cast<char*>(p), want, bytes});
+  *out = p;
+  return 0;
+}
+
+int Arena::reset() {
+  if (chunks_.size() > 1) {
+    size_t total = 0;
+    for (auto& c : chunks_) {
+      total += c.size;
+      (void)hipFree(c.base);
+    }
+    chunks_.clear();
+    void* p = nullptr;
+    if (hipMalloc(&p, total) == hipSuccess) chunks_.push_back({static_cast<char*>(p), total, 0});
+  } else if (chunks_.size() == 1) {
+    chunks_[0].used = 0;
+  }
+  return 0;
+}
+
+void Arena::destroy() {
+  for (auto& c : chunks_) (void)hipFree(c.base);
+  chunks_.clear();
+}
+
+// ---- contexts -----------------------------------------------------------
+
+static std::mutex g_mu;
+static std::map<int, Ctx*> g_ctx;
+
+Ctx* ctx_for(int device) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_ctx.find(device);
+  if (it != g_ctx.end()) {
+    (void)hipSetDevice(device);
+    return it->second;
+  }
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    set_error("no HIP device available (%s)", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+    return nullptr;
+  }
+  if (device < 0 || device >= n) {
+    set_error("device %d out of range (have %d)", device, n);
+    return nullptr;
+  }
+  if ((e = hipSetDevice(device)) != hipSuccess) {
+    set_error("hipSetDevice(%d): %s", device, hipGetErrorString(e));
+    return nullptr;
+  }
+  Ctx* c = new Ctx();
+  c->device = device;
+  if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
+    set_error("hipStreamCreate: %s", hipGetErrorString(e));
+    delete c;
+    return nullptr;
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->cu_count = prop.multiProcessorCount;
+  g_ctx[device] = c;
+  return c;
+}
+
+// ---- timers ---------------------------------------------------------------
+
+ProfScope::ProfScope(Ctx* c, const char* name) : c_(c) {
+  if (!c->prof) return;
+  t_ = &c->timers[name];
+  hipEvent_t a = nullptr, b = nullptr;
+  if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+    t_ = nullptr;
+    return;
+  }
+  start_ = a;
+  (void)hipEventRecord(a, c->stream);
+  t_->pending.emplace_back(a, b);
+}
+
+ProfScope::~ProfScope() {
+  if (!t_) return;
+  (void)hipEventRecord(t_->pending.back().second, c_->stream);
+}
+
+static void drain_timers(Ctx* c) {
+  (void)hipStreamSynchronize(c->stream);
+  for (auto& kv : c->timers) {
+    Timer& t = kv.second;
+    for (auto& ev : t.pending) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) {
+        t.ms += ms;
+        t.launches += 1;
+      }
+      (void)hipEventDestroy(ev.first);
+      (void)hipEventDestroy(ev.second);
+    }
+    t.pending.clear();
+  }
+}
+
+}  // namespace pyqsm
+
+using namespace pyqsm;
+
+extern "C" {
+
+int pyqsm_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int pyqsm_init(int device) { return ctx_for(device) ? 0 : PYQSM_ENODEV; }
+
+int pyqsm_shutdown(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (auto& kv : g_ctx) {
+    Ctx* c = kv.second;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    drain_timers(c);
+    c->arena.destroy();
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+  }
+  g_ctx.clear();
+  return 0;
+}
+
+const char* pyqsm_last_error(void) { return g_err; }
+
+const char* pyqsm_version(void) { return "pyqsm_hip 0.1.0 gfx950"; }
+
+int pyqsm_sync(int device) {
+  Ctx* c = ctx_for(device);
+  if (!c) return PYQSM_ENODEV;
+  PQ_HIP(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+void* pyqsm_stream(int device) {
+  Ctx* c = ctx_for(device);
+  return c ? static_cast<void*>(c->stream) : nullptr;
+}
+
+int pyqsm_dev_malloc(int device, size_t bytes, void** out) {
+  if (!out) return fail(PYQSM_EINVAL, "pyqsm_dev_malloc: out is NULL");
+  Ctx* c = ctx_for(device);
+  if (!c) return PYQSM_ENODEV;
+  PQ_HIP(hipMalloc(out, bytes ? bytes : 1));
+  return 0;
+}
+
+int pyqsm_dev_free(int device, void* p) {
+  Ctx* c = ctx_for(device);
+  if (!c) return PYQSM_ENODEV;
+  if (p) PQ_HIP(hipFree(p));
+  return 0;
+}
+
+int pyqsm_h2d(int device, void* dst, const void* src, size_t bytes) {
+  Ctx* c = ctx_for(device);
+  if (!c) return PYQSM_ENODEV;
+  if (bytes == 0) return 0;
+  if (!dst || !src) return fail(PYQSM_EINVAL, "pyqsm_h2d: NULL pointer");
+  PQ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+  PQ_HIP(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int pyqsm_d2h(int device, void* dst, const void* src, size_t bytes) {
+  Ctx* c = ctx_for(device);
+  if (!c) return PYQSM_ENODEV;
+  if (bytes == 0) return 0;
+  if (!dst || !src) return fail(PYQSM_EINVAL, "pyqsm_d2h: NULL pointer");
+  PQ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+  PQ_HIP(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+void pyqsm_free(void* p) { free(p); }
+
+int pyqsm_prof_enable(int device, int on) {
+  Ctx* c = ctx_for(device);
+  if (!c) return PYQSM_ENODEV;
+  std::lock_guard<std::mutex> lk(c->mu);
+  c->prof = on != 0;
+  return 0;
+}
+
+int pyqsm_prof_reset(int device) {
+  Ctx* c = ctx_for(device);
+  if (!c) return PYQSM_ENODEV;
+  std::lock_guard<std::mutex> lk(c->mu);
+  drain_timers(c);
+  c->timers.clear();
+  return 0;
+}
+
+int pyqsm_prof_get(int device, const char* name, double* total_ms, int64_t* launches) {
+  Ctx* c = ctx_for(device);
+  if (!c) return PYQSM_ENODEV;
+  if (!name) return fail(PYQSM_EINVAL, "pyqsm_prof_get: name is NULL");
+  std::lock_guard<std::mutex> lk(c->mu);
+  drain_timers(c);
+  auto it = c->timers.find(name);
+  if (total_ms) *total_ms = it == c->timers.end() ? 0.0 : it->second.ms;
+  if (launches) *launches = it == c->timers.end() ? 0 : it->second.launches;
+  return 0;
+}
+
+}  // extern "C"

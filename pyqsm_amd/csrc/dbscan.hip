@@ -1,0 +1,280 @@
+// dbscan.hip — eps-neighbourhood clustering on gfx950, bit-exact with
+// scikit-learn's DBSCAN (pyQSM/math_utils/fit.py:223) and usable for Open3D's
+// cluster_dbscan call sites (pyQSM/geometry/point_cloud_processing.py:185,209).
+//
+// Parallel formulation of the sequential reference:
+//   1. bin points into cells of edge >= eps (grid.hip)
+//   2. core(i)  <=> #{ j in 27-cell stencil : d2(i,j) <= eps^2 } >= min_pts
+//   3. union-find over core-core pairs within eps (lock-free hooking, larger
+//      root under smaller, agent-scope atomics)
+//   4. cluster number = rank of the component's smallest ORIGINAL core index
+//      (what the index-order seeding of the sequential algorithm produces)
+//   5. border point -> smallest cluster number among its core neighbours
+// The distance predicate is evaluated in fp64 exactly as scikit-learn does:
+// d2 = ((dx*dx) + dy*dy) + dz*dz with separately rounded products, compared
+// with fl(eps*eps). The library is compiled with -ffp-contract=off.
+#include "grid.hpp"
+
+namespace pyqsm {
+
+static constexpr int kNoRoot = 0x7FFFFFFF;
+
+__device__ __forceinline__ double sqdist(double ax, double ay, double az, double bx, double by,
+                                         double bz) {
+  double t0 = ax - bx, t1 = ay - by, t2 = az - bz;
+  double d = t0 * t0;
+  d = d + t1 * t1;
+  d = d + t2 * t2;
+  return d;
+}
+
+struct Stencil {
+  int nx, nxy;
+};
+
+// Visit every sorted position q in the 27-cell stencil of cell c:
+// nine contiguous runs (x-1..x+1 for each of the 3x3 (y,z) rows).
+#define FOR_STENCIL(c, st, start, q, body)                         \
+  for (int dz__ = -1; dz__ <= 1; ++dz__)                           \
+    for (int dy__ = -1; dy__ <= 1; ++dy__) {                       \
+      const int row__ = (c) + dy__ * (st).nx + dz__ * (st).nxy;    \
+      const int qb__ = (start)[row__ - 1], qe__ = (start)[row__ + 2]; \
+      for (int q = qb__; q < qe__; ++q) {                          \
+        body                                                       \
+      }                                                            \
+    }
+
+__global__ __launch_bounds__(256) void k_core(int n, Stencil st, const int32_t* __restrict__ start,
+                                              const int32_t* __restrict__ cell_of,
+                                              const double* __restrict__ sx,
+                                              const double* __restrict__ sy,
+                                              const double* __restrict__ sz, double r2,
+                                              int min_pts, uint8_t* __restrict__ core) {
+  int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= n) return;
+  const double x = sx[p], y = sy[p], z = sz[p];
+  const int c = cell_of[p];
+  int cnt = 0;
+  FOR_STENCIL(c, st, start, q, { cnt += sqdist(x, y, z, sx[q], sy[q], sz[q]) <= r2; })
+  core[p] = cnt >= min_pts;
+}
+
+// ---- union-find --------------------------------------------------------------
+
+__device__ __forceinline__ int ld_parent(const int* parent, int i) {
+  return __hip_atomic_load(parent + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_parent(int* parent, int i, int v) {
+  __hip_atomic_store(parent + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Parent pointers only ever decrease (a root is hooked under a smaller root), so
+// every pointer names an ancestor and halving a path is always safe.
+__device__ __forceinline__ int find_root(int* parent, int x) {
+  int cur = ld_parent(parent, x);
+  if (cur != x) {
+    int prev = x, next;
+    while (cur > (next = ld_parent(parent, cur))) {
+      st_parent(parent, prev, next);
+      prev = cur;
+      cur = next;
+    }
+  }
+  return cur;
+}
+
+__device__ __forceinline__ void unite(int* parent, int a, int b) {
+  int ra = find_root(parent, a), rb = find_root(parent, b);
+  while (ra != rb) {
+    if (ra < rb) {
+      int t = ra;
+      ra = rb;
+      rb = t;
+    }
+    // hook the larger root under the smaller one
+    int old = atomicCAS(parent + ra, ra, rb);
+    if (old == ra) break;
+    ra = old;  // lost the race: ra already has a (smaller) parent, climb
+  }
+}
+
+__global__ __launch_bounds__(256) void k_init_parent(int n, int* __restrict__ parent) {
+  int p = blockIdx.x * 256 + threadIdx.x;
+  if (p < n) parent[p] = p;
+}
+
+__global__ __launch_bounds__(256) void k_union(int n, Stencil st, const int32_t* __restrict__ start,
+                                               const int32_t* __restrict__ cell_of,
+                                               const double* __restrict__ sx,
+                                               const double* __restrict__ sy,
+                                               const double* __restrict__ sz, double r2,
+                                               const uint8_t* __restrict__ core, int* parent) {
+  int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= n || !core[p]) return;
+  const double x = sx[p], y = sy[p], z = sz[p];
+  const int c = cell_of[p];
+  FOR_STENCIL(c, st, start, q, {
+    // each unordered pair once
+    if (q < p && core[q] && sqdist(x, y, z, sx[q], sy[q], sz[q]) <= r2) {
+      if (ld_parent(parent, q) != ld_parent(parent, p)) unite(parent, p, q);
+    }
+  })
+}
+
+// root[p] for core points, then the smallest original index of each component.
+__global__ __launch_bounds__(256) void k_flatten(int n, const uint8_t* __restrict__ core,
+                                                 int* __restrict__ parent,
+                                                 const int32_t* __restrict__ order,
+                                                 int* __restrict__ min_orig) {
+  int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= n || !core[p]) return;
+  int r = p;
+  for (int nx = parent[r]; nx != r; nx = parent[r]) r = nx;  // plain loads: kernel boundary
+  parent[p] = r;  // benign: r is still an ancestor for concurrent readers
+  atomicMin(min_orig + r, order[p]);
+}
+
+__global__ __launch_bounds__(256) void k_mark_roots(int n, const uint8_t* __restrict__ core,
+                                                    const int* __restrict__ parent,
+                                                    const int* __restrict__ min_orig,
+                                                    int32_t* __restrict__ flag) {
+  int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= n || !core[p]) return;
+  if (parent[p] == p) flag[min_orig[p]] = 1;
+}
+
+__global__ __launch_bounds__(256) void k_labels(int n, Stencil st,
+                                                const int32_t* __restrict__ start,
+                                                const int32_t* __restrict__ cell_of,
+                                                const double* __restrict__ sx,
+                                                const double* __restrict__ sy,
+                                                const double* __restrict__ sz, double r2,
+                                                const uint8_t* __restrict__ core,
+                                                const int* __restrict__ parent,
+                                                const int* __restrict__ min_orig,
+                                                const int32_t* __restrict__ rank,
+                                                const int32_t* __restrict__ order,
+                                                int64_t* __restrict__ labels,
+                                                uint8_t* __restrict__ is_core) {
+  int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= n) return;
+  int best = kNoRoot;
+  if (core[p]) {
+    best = min_orig[parent[p]];
+  } else {
+    const double x = sx[p], y = sy[p], z = sz[p];
+    const int c = cell_of[p];
+    FOR_STENCIL(c, st, start, q, {
+      if (core[q] && sqdist(x, y, z, sx[q], sy[q], sz[q]) <= r2) {
+        int m = min_orig[parent[q]];
+        best = m < best ? m : best;
+      }
+    })
+  }
+  const int o = order[p];
+  labels[o] = best == kNoRoot ? int64_t(-1) : int64_t(rank[best]);
+  if (is_core) is_core[o] = core[p];
+}
+
+static int dbscan_device(Ctx* c, const double* xyz, int64_t n, double eps, int32_t min_pts,
+                         int64_t* labels, uint8_t* is_core, int64_t* n_clusters) {
+  if (!(eps > 0) || !std::isfinite(eps)) return fail(PYQSM_EINVAL, "eps must be positive");
+  if (n == 0) {
+    if (n_clusters) *n_clusters = 0;
+    return 0;
+  }
+  DevGrid g;
+  {
+    ProfScope ps(c, "dbscan_bin");
+    // a hair wider than eps: rounding of the cell index can then never put two
+    // points that are within eps of each other two cells apart
+    PQ_TRY(build_grid(c, xyz, n, eps * (1.0 + 1.0 / 1048576.0), int64_t(1) << 28, &g));
+  }
+  const int N = int(n);
+  const dim3 grid(ceil_div(n, 256)), block(256);
+  const Stencil st{g.nx, g.nx * g.ny};
+  const double r2 = eps * eps;
+  uint8_t* core;
+  int *parent, *min_orig;
+  int32_t* flag;
+  PQ_TRY(c->arena.get(size_t(n), &core));
+  PQ_TRY(c->arena.get(size_t(n), &parent));
+  PQ_TRY(c->arena.get(size_t(n), &min_orig));
+  PQ_TRY(c->arena.get(size_t(n) + 1, &flag));
+  {
+    ProfScope ps(c, "dbscan_core");
+    hipLaunchKernelGGL(k_core, grid, block, 0, c->stream, N, st, g.start, g.cell_of, g.sx, g.sy,
+                       g.sz, r2, min_pts, core);
+    PQ_HIP(hipGetLastError());
+  }
+  {
+    ProfScope ps(c, "dbscan_union");
+    hipLaunchKernelGGL(k_init_parent, grid, block, 0, c->stream, N, parent);
+    PQ_HIP(hipMemsetAsync(min_orig, 0x7F, size_t(n) * 4, c->stream));  // 0x7F7F7F7F > any index
+    PQ_HIP(hipMemsetAsync(flag, 0, (size_t(n) + 1) * 4, c->stream));
+    hipLaunchKernelGGL(k_union, grid, block, 0, c->stream, N, st, g.start, g.cell_of, g.sx, g.sy,
+                       g.sz, r2, core, parent);
+    PQ_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_flatten, grid, block, 0, c->stream, N, core, parent, g.order, min_orig);
+    hipLaunchKernelGGL(k_mark_roots, grid, block, 0, c->stream, N, core, parent, min_orig, flag);
+    PQ_HIP(hipGetLastError());
+    PQ_TRY(exclusive_scan_i32(c, flag, n + 1));
+  }
+  {
+    ProfScope ps(c, "dbscan_label");
+    hipLaunchKernelGGL(k_labels, grid, block, 0, c->stream, N, st, g.start, g.cell_of, g.sx, g.sy,
+                       g.sz, r2, core, parent, min_orig, flag, g.order, labels, is_core);
+    PQ_HIP(hipGetLastError());
+  }
+  if (n_clusters) {
+    int32_t h = 0;
+    PQ_HIP(hipMemcpyAsync(&h, flag + n, 4, hipMemcpyDeviceToHost, c->stream));
+    PQ_HIP(hipStreamSynchronize(c->stream));
+    *n_clusters = h;
+  }
+  return 0;
+}
+
+}  // namespace pyqsm
+
+using namespace pyqsm;
+
+extern "C" {
+
+int pyqsm_dbscan_dev(const double* xyz_dev, int64_t n, double eps, int32_t min_pts,
+                     int64_t* labels_dev, uint8_t* is_core_dev, int64_t* n_clusters,
+                     int32_t device) {
+  if (n < 0) return fail(PYQSM_EINVAL, "negative size");
+  if (n > 0 && (!xyz_dev || !labels_dev)) return fail(PYQSM_EINVAL, "pyqsm_dbscan_dev: NULL pointer");
+  Ctx* c = ctx_for(device);
+  if (!c) return PYQSM_ENODEV;
+  std::lock_guard<std::mutex> lk(c->mu);
+  c->arena.reset();
+  ProfScope ps(c, "dbscan_total");
+  return dbscan_device(c, xyz_dev, n, eps, min_pts, labels_dev, is_core_dev, n_clusters);
+}
+
+int pyqsm_dbscan(const double* xyz, int64_t n, double eps, int32_t min_pts, int64_t* labels,
+                 uint8_t* is_core, int32_t device) {
+  if (n < 0) return fail(PYQSM_EINVAL, "negative size");
+  if (n == 0) return 0;
+  if (!xyz || !labels) return fail(PYQSM_EINVAL, "pyqsm_dbscan: NULL pointer");
+  Ctx* c = ctx_for(device);
+  if (!c) return PYQSM_ENODEV;
+  std::lock_guard<std::mutex> lk(c->mu);
+  c->arena.reset();
+  double* d_xyz;
+  int64_t* d_lab;
+  uint8_t* d_core;
+  PQ_TRY(c->arena.get(size_t(n) * 3, &d_xyz));
+  PQ_TRY(c->arena.get(size_t(n), &d_lab));
+  PQ_TRY(c->arena.get(size_t(n), &d_core));
+  PQ_HIP(hipMemcpyAsync(d_xyz, xyz, size_t(n) * 24, hipMemcpyHostToDevice, c->stream));
+  PQ_TRY(dbscan_device(c, d_xyz, n, eps, min_pts, d_lab, d_core, nullptr));
+  PQ_HIP(hipMemcpyAsync(labels, d_lab, size_t(n) * 8, hipMemcpyDeviceToHost, c->stream));
+  if (is_core) PQ_HIP(hipMemcpyAsync(is_core, d_core, size_t(n), hipMemcpyDeviceToHost, c->stream));
+  PQ_HIP(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,190 @@
+// grid.hip — bounding box, cell counting sort (see grid.hpp).
+#include "grid.hpp"
+
+#include <cmath>
+
+namespace pyqsm {
+
+// Order-preserving map double -> uint64 so that atomicMin/atomicMax work.
+__device__ __forceinline__ unsigned long long ord_key(double x) {
+  unsigned long long b = static_cast<unsigned long long>(__double_as_longlong(x));
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+static double ord_val(unsigned long long k) {
+  unsigned long long b = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
+  double d;
+  memcpy(&d, &b, 8);
+  return d;
+}
+
+__global__ __launch_bounds__(256) void k_bbox(const double* __restrict__ xyz, int64_t n,
+                                              unsigned long long* __restrict__ out /*[6]*/) {
+  unsigned long long mn[3] = {~0ull, ~0ull, ~0ull}, mx[3] = {0, 0, 0};
+  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < n;
+       i += int64_t(gridDim.x) * blockDim.x) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      unsigned long long k = ord_key(xyz[3 * i + a]);
+      mn[a] = k < mn[a] ? k : mn[a];
+      mx[a] = k > mx[a] ? k : mx[a];
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      unsigned long long o1 = __shfl_down(mn[a], off, 64), o2 = __shfl_down(mx[a], off, 64);
+      mn[a] = o1 < mn[a] ? o1 : mn[a];
+      mx[a] = o2 > mx[a] ? o2 : mx[a];
+    }
+  }
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      atomicMin(&out[a], mn[a]);
+      atomicMax(&out[3 + a], mx[a]);
+    }
+  }
+}
+
+struct GridParams {
+  double minx, miny, minz, inv_cell;
+  int nx, ny, nz;
+};
+
+__device__ __forceinline__ int cell_index(const GridParams& g, double x, double y, double z) {
+  // interior cells are 1 .. n-2; clamp guards the max-boundary point
+  int cx = int(floor((x - g.minx) * g.inv_cell)) + 1;
+  int cy = int(floor((y - g.miny) * g.inv_cell)) + 1;
+  int cz = int(floor((z - g.minz) * g.inv_cell)) + 1;
+  cx = cx < 1 ? 1 : (cx > g.nx - 2 ? g.nx - 2 : cx);
+  cy = cy < 1 ? 1 : (cy > g.ny - 2 ? g.ny - 2 : cy);
+  cz = cz < 1 ? 1 : (cz > g.nz - 2 ? g.nz - 2 : cz);
+  return (cz * g.ny + cy) * g.nx + cx;
+}
+
+__global__ __launch_bounds__(256) void k_cell_count(const double* __restrict__ xyz, int64_t n,
+                                                    GridParams g, int32_t* __restrict__ counts,
+                                                    int32_t* __restrict__ cell_tmp,
+                                                    int32_t* __restrict__ rank_tmp) {
+  int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+  if (i >= n) return;
+  int c = cell_index(g, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
+  cell_tmp[i] = c;
+  rank_tmp[i] = atomicAdd(&counts[c], 1);
+}
+
+__global__ __launch_bounds__(256) void k_cell_scatter(const double* __restrict__ xyz, int64_t n,
+                                                      const int32_t* __restrict__ start,
+                                                      const int32_t* __restrict__ cell_tmp,
+                                                      const int32_t* __restrict__ rank_tmp,
+                                                      int32_t* __restrict__ order,
+                                                      int32_t* __restrict__ cell_of,
+                                                      double* __restrict__ sx,
+                                                      double* __restrict__ sy,
+                                                      double* __restrict__ sz) {
+  int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+  if (i >= n) return;
+  int c = cell_tmp[i];
+  int p = start[c] + rank_tmp[i];
+  order[p] = int32_t(i);
+  cell_of[p] = c;
+  sx[p] = xyz[3 * i];
+  sy[p] = xyz[3 * i + 1];
+  sz[p] = xyz[3 * i + 2];
+}
+
+__global__ __launch_bounds__(256) void k_count_occupied(const int32_t* __restrict__ start,
+                                                        int64_t ncell, int32_t* __restrict__ out) {
+  int32_t local = 0;
+  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < ncell;
+       i += int64_t(gridDim.x) * blockDim.x)
+    local += start[i + 1] > start[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
+  if ((threadIdx.x & 63) == 0 && local) atomicAdd(out, local);
+}
+
+int build_grid(Ctx* c, const double* xyz, int64_t n, double min_cell, int64_t max_cells,
+               DevGrid* g) {
+  if (n <= 0) return fail(PYQSM_EINVAL, "build_grid: empty cloud");
+  if (n > 0x7FFFFF00LL) return fail(PYQSM_ERANGE, "more than 2^31 points per call");
+  if (!(min_cell > 0) || !std::isfinite(min_cell))
+    return fail(PYQSM_EINVAL, "cell edge must be positive and finite");
+  unsigned long long* d_box = nullptr;
+  PQ_TRY(c->arena.get(6, &d_box));
+  unsigned long long init[6] = {~0ull, ~0ull, ~0ull, 0, 0, 0};
+  PQ_HIP(hipMemcpyAsync(d_box, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+  const int blocks = int(std::min<int64_t>(ceil_div(n, 256), int64_t(c->cu_count) * 8));
+  hipLaunchKernelGGL(k_bbox, dim3(blocks), dim3(256), 0, c->stream, xyz, n, d_box);
+  PQ_HIP(hipGetLastError());
+  unsigned long long h_box[6];
+  PQ_HIP(hipMemcpyAsync(h_box, d_box, sizeof(h_box), hipMemcpyDeviceToHost, c->stream));
+  PQ_HIP(hipStreamSynchronize(c->stream));
+  double mn[3], mx[3];
+  for (int a = 0; a < 3; ++a) {
+    mn[a] = ord_val(h_box[a]);
+    mx[a] = ord_val(h_box[3 + a]);
+    if (!std::isfinite(mn[a]) || !std::isfinite(mx[a]))
+      return fail(PYQSM_EINVAL, "point coordinates must be finite");
+  }
+  double cell = min_cell;
+  int dims[3];
+  for (;;) {
+    double tot = 1.0;
+    bool ok = true;
+    for (int a = 0; a < 3; ++a) {
+      double d = std::floor((mx[a] - mn[a]) / cell) + 3.0;  // +1 interior, +2 border
+      if (!(d < 2.0e9)) ok = false;
+      dims[a] = ok ? int(d) : 0;
+      tot *= d;
+    }
+    if (ok && tot <= double(max_cells)) break;
+    cell *= 2.0;
+  }
+  g->minx = mn[0];
+  g->miny = mn[1];
+  g->minz = mn[2];
+  g->cell = cell;
+  g->inv_cell = 1.0 / cell;
+  g->nx = dims[0];
+  g->ny = dims[1];
+  g->nz = dims[2];
+  g->ncell = int64_t(dims[0]) * dims[1] * dims[2];
+  int32_t *cell_tmp, *rank_tmp;
+  PQ_TRY(c->arena.get(size_t(g->ncell) + 1, &g->start));
+  PQ_TRY(c->arena.get(size_t(n), &g->order));
+  PQ_TRY(c->arena.get(size_t(n), &g->cell_of));
+  PQ_TRY(c->arena.get(size_t(n), &g->sx));
+  PQ_TRY(c->arena.get(size_t(n), &g->sy));
+  PQ_TRY(c->arena.get(size_t(n), &g->sz));
+  PQ_TRY(c->arena.get(size_t(n), &cell_tmp));
+  PQ_TRY(c->arena.get(size_t(n), &rank_tmp));
+  PQ_HIP(hipMemsetAsync(g->start, 0, (size_t(g->ncell) + 1) * 4, c->stream));
+  GridParams gp{g->minx, g->miny, g->minz, g->inv_cell, g->nx, g->ny, g->nz};
+  const dim3 grid(ceil_div(n, 256));
+  hipLaunchKernelGGL(k_cell_count, grid, dim3(256), 0, c->stream, xyz, n, gp, g->start, cell_tmp,
+                     rank_tmp);
+  PQ_HIP(hipGetLastError());
+  PQ_TRY(exclusive_scan_i32(c, g->start, g->ncell + 1));
+  hipLaunchKernelGGL(k_cell_scatter, grid, dim3(256), 0, c->stream, xyz, n, g->start, cell_tmp,
+                     rank_tmp, g->order, g->cell_of, g->sx, g->sy, g->sz);
+  PQ_HIP(hipGetLastError());
+  return 0;
+}
+
+int count_occupied(Ctx* c, const DevGrid& g, int64_t* occupied) {
+  int32_t* d = nullptr;
+  PQ_TRY(c->arena.get(1, &d));
+  PQ_HIP(hipMemsetAsync(d, 0, 4, c->stream));
+  const int blocks = int(std::min<int64_t>(ceil_div(g.ncell, 256), int64_t(c->cu_count) * 8));
+  hipLaunchKernelGGL(k_count_occupied, dim3(blocks), dim3(256), 0, c->stream, g.start, g.ncell, d);
+  PQ_HIP(hipGetLastError());
+  int32_t h = 0;
+  PQ_HIP(hipMemcpyAsync(&h, d, 4, hipMemcpyDeviceToHost, c->stream));
+  PQ_HIP(hipStreamSynchronize(c->stream));
+  *occupied = h;
+  return 0;
+}
+
+}  // namespace pyqsm

@@ -1,0 +1,37 @@
+// grid.hpp — uniform cell grid over a point cloud in HBM: the binning step that
+// the eps-neighbourhood (DBSCAN) and kNN kernels share.
+//
+// Layout: cells are row-major with x fastest and carry a one-cell empty border,
+// so the 3x3x3 stencil of any point is nine contiguous runs of the sorted point
+// array: [start[row + cx - 1], start[row + cx + 2]) for each of the 9 (y,z) rows.
+// Points are counting-sorted by cell into SoA coordinate arrays (coalesced,
+// 8-byte loads per lane).
+#pragma once
+#include "common.hpp"
+
+namespace pyqsm {
+
+struct DevGrid {
+  double minx, miny, minz;
+  double inv_cell;
+  double cell;
+  int nx, ny, nz;        // including the border cells
+  int64_t ncell;         // nx*ny*nz
+  int32_t* start;        // [ncell + 1] first sorted position of each cell
+  int32_t* order;        // [n] sorted position -> original index
+  int32_t* cell_of;      // [n] cell id of each sorted position
+  double *sx, *sy, *sz;  // [n] sorted coordinates
+};
+
+// Builds the grid for n points (f64 [n,3], device) with cells of at least
+// `min_cell` edge (the edge is doubled until the dense grid has at most
+// `max_cells` cells). All arrays come from the context arena. Synchronises the
+// stream once (bounding box read-back). Fails with PYQSM_EINVAL on non-finite
+// coordinates.
+int build_grid(Ctx* c, const double* xyz, int64_t n, double min_cell, int64_t max_cells,
+               DevGrid* g);
+
+// Number of occupied cells (reads back one int; synchronises).
+int count_occupied(Ctx* c, const DevGrid& g, int64_t* occupied);
+
+}  // namespace pyqsm

@@ -1,0 +1,486 @@
+// raycast.hip — BVH-free ray x triangle sweep (Moller-Trumbore, closest hit,
+// all hits, crossing counts) for gfx950.
+//
+// Replaces open3d RaycastingScene.cast_rays / list_intersections /
+// compute_occupancy as used by pyQSM/viz/ray_casting.py:275-279,168,65-69.
+//
+// Data flow: the mesh is expanded once to 48-byte records (v0, e1, e2, pad) and
+// every wave walks the whole record array in triangle order. The record index is
+// wave-uniform, so the records arrive through the scalar cache as SGPR operands
+// and never occupy VGPRs or LDS; each lane keeps RPL rays in registers and
+// evaluates two rays per packed-f32 instruction. Nothing but the rays (read
+// once) and the results (written once) touches HBM per ray; the 24 MB record
+// stream is shared by every CU and is served from L2 / Infinity Cache.
+//
+// Arithmetic contract (shared with oracle/pyqsm_oracle.c, which restates it on
+// the CPU so that t, u, v and the primitive id agree bit for bit):
+//   p  = d x e2          px = fma(dy, e2z, -(dz*e2y)) ...
+//   det = fma(e1x, px, fma(e1y, py, e1z*pz))
+//   tv = o - v0
+//   U  = fma(tvx, px, fma(tvy, py, tvz*pz))
+//   q  = tv x e1         qx = fma(tvy, e1z, -(tvz*e1y)) ...
+//   V  = fma(dx, qx, fma(dy, qy, dz*qz))
+//   Tn = fma(e2x, qx, fma(e2y, qy, e2z*qz))
+//   W  = det - (U + V)
+//   hit <=> (det > 0 & U >= 0 & V >= 0 & W >= 0 & Tn > 0)
+//         | (det < 0 & U <= 0 & V <= 0 & W <= 0 & Tn < 0)
+//   t = Tn / det, u = U / det, v = V / det   (IEEE division)
+//   closest hit: strictly smaller t wins, so ties go to the lowest triangle id.
+#include "common.hpp"
+
+namespace pyqsm {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 splat(float s) { return f2{s, s}; }
+
+struct alignas(16) TriRec {  // 48 bytes, 16-byte aligned
+  float v0x, v0y, v0z, e1x;
+  float e1y, e1z, e2x, e2y;
+  float e2z, pad0, pad1, pad2;
+};
+
+// The nine live floats of a record, as separate scalars (kept in SGPRs when the
+// record index is wave-uniform).
+struct Tri {
+  float v0x, v0y, v0z, e1x, e1y, e1z, e2x, e2y, e2z;
+};
+
+__device__ __forceinline__ Tri load_tri(const TriRec* __restrict__ tri, int j) {
+  const float4* p = reinterpret_cast<const float4*>(tri + j);
+  const float4 a = p[0], b = p[1], c = p[2];
+  return Tri{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x};
+}
+
+// ---- mesh expansion ---------------------------------------------------------
+
+__global__ void k_expand_tris(const float* __restrict__ verts, int64_t V,
+                              const int32_t* __restrict__ tris, int64_t T,
+                              TriRec* __restrict__ out, int* __restrict__ bad) {
+  int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+  if (i >= T) return;
+  int32_t a = tris[3 * i], b = tris[3 * i + 1], c = tris[3 * i + 2];
+  if (a < 0 || b < 0 || c < 0 || a >= V || b >= V || c >= V) {
+    *bad = 1;
+    a = b = c = 0;
+  }
+  float ax = verts[3 * a], ay = verts[3 * a + 1], az = verts[3 * a + 2];
+  TriRec r;
+  r.v0x = ax;
+  r.v0y = ay;
+  r.v0z = az;
+  r.e1x = verts[3 * b] - ax;
+  r.e1y = verts[3 * b + 1] - ay;
+  r.e1z = verts[3 * b + 2] - az;
+  r.e2x = verts[3 * c] - ax;
+  r.e2y = verts[3 * c + 1] - ay;
+  r.e2z = verts[3 * c + 2] - az;
+  r.pad0 = r.pad1 = r.pad2 = 0.f;
+  out[i] = r;
+}
+
+// ---- the sweep ----------------------------------------------------------------
+
+struct RayPair {  // two rays, one per packed half
+  f2 ox, oy, oz, dx, dy, dz;
+};
+
+// Numerators of one triangle against one ray pair.
+struct Num {
+  f2 det, U, V, Tn;
+};
+
+__device__ __forceinline__ void mt_front(const RayPair& r, const Tri t, f2& px, f2& py,
+                                         f2& pz, f2& det, f2& tvx, f2& tvy, f2& tvz, f2& U) {
+  px = fma2(r.dy, splat(t.e2z), -(r.dz * splat(t.e2y)));
+  py = fma2(r.dz, splat(t.e2x), -(r.dx * splat(t.e2z)));
+  pz = fma2(r.dx, splat(t.e2y), -(r.dy * splat(t.e2x)));
+  det = fma2(splat(t.e1x), px, fma2(splat(t.e1y), py, splat(t.e1z) * pz));
+  tvx = r.ox - splat(t.v0x);
+  tvy = r.oy - splat(t.v0y);
+  tvz = r.oz - splat(t.v0z);
+  U = fma2(tvx, px, fma2(tvy, py, tvz * pz));
+}
+
+__device__ __forceinline__ void mt_back(const RayPair& r, const Tri t, f2 tvx, f2 tvy,
+                                        f2 tvz, f2& V, f2& Tn) {
+  f2 qx = fma2(tvy, splat(t.e1z), -(tvz * splat(t.e1y)));
+  f2 qy = fma2(tvz, splat(t.e1x), -(tvx * splat(t.e1z)));
+  f2 qz = fma2(tvx, splat(t.e1y), -(tvy * splat(t.e1x)));
+  V = fma2(r.dx, qx, fma2(r.dy, qy, r.dz * qz));
+  Tn = fma2(splat(t.e2x), qx, fma2(splat(t.e2y), qy, splat(t.e2z) * qz));
+}
+
+// Can this (det, U) still be a hit? A hit needs 0 <= U/det <= 1 (W >= 0 with
+// V >= 0 gives |U| <= |det|; fl(U + V) is monotone so this survives rounding),
+// i.e. |2U - det| <= |det|. One fma and one compare per ray; false positives at
+// rounding edges are harmless because is_hit() makes the exact decision.
+__device__ __forceinline__ f2 alive_key(f2 det, f2 U) { return fma2(splat(2.f), U, -det); }
+__device__ __forceinline__ bool u_alive(float key, float det) {
+  return __builtin_fabsf(key) <= __builtin_fabsf(det);
+}
+
+__device__ __forceinline__ bool is_hit(float det, float U, float V, float Tn) {
+  float W = det - (U + V);
+  bool pos = det > 0.f && U >= 0.f && V >= 0.f && W >= 0.f && Tn > 0.f;
+  bool neg = det < 0.f && U <= 0.f && V <= 0.f && W <= 0.f && Tn < 0.f;
+  return pos || neg;
+}
+
+// NP = ray pairs per lane (each lane owns 2*NP rays).
+template <int NP>
+__global__ __launch_bounds__(256) void k_cast_rays(const TriRec* __restrict__ tri, int T,
+                                                   const float* __restrict__ rays, int64_t R,
+                                                   float* __restrict__ t_hit,
+                                                   uint32_t* __restrict__ prim_id,
+                                                   float* __restrict__ uv) {
+  constexpr int RPL = 2 * NP;
+  const int64_t block_base = int64_t(blockIdx.x) * (256 * RPL);
+  RayPair rp[NP];
+  float best_t[RPL];
+  uint32_t best_p[RPL];
+#pragma unroll
+  for (int k = 0; k < RPL; ++k) {
+    int64_t r = block_base + int64_t(k) * 256 + threadIdx.x;
+    float o0 = 0.f, o1 = 0.f, o2 = 0.f, d0 = 0.f, d1 = 0.f, d2 = 0.f;
+    if (r < R) {
+      const float* p = rays + 6 * r;
+      o0 = p[0]; o1 = p[1]; o2 = p[2]; d0 = p[3]; d1 = p[4]; d2 = p[5];
+    }
+    rp[k >> 1].ox[k & 1] = o0; rp[k >> 1].oy[k & 1] = o1; rp[k >> 1].oz[k & 1] = o2;
+    rp[k >> 1].dx[k & 1] = d0; rp[k >> 1].dy[k & 1] = d1; rp[k >> 1].dz[k & 1] = d2;
+    best_t[k] = __builtin_inff();
+    best_p[k] = PYQSM_MISS_PRIM;
+  }
+
+  Tri nxt = load_tri(tri, 0);  // T >= 1 is checked by the launcher
+  for (int j = 0; j < T; ++j) {
+    // Wave-uniform address: the record arrives by scalar loads. The next record
+    // is requested before this one is consumed so its latency is covered.
+    const Tri t = nxt;
+    nxt = load_tri(tri, j + 1 < T ? j + 1 : j);
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      f2 px, py, pz, det, tvx, tvy, tvz, U;
+      mt_front(rp[q], t, px, py, pz, det, tvx, tvy, tvz, U);
+      const f2 key = alive_key(det, U);
+      bool alive = u_alive(key[0], det[0]) || u_alive(key[1], det[1]);
+      if (__builtin_amdgcn_ballot_w64(alive) != 0) {  // wave-uniform branch
+        f2 V, Tn;
+        mt_back(rp[q], t, tvx, tvy, tvz, V, Tn);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          if (is_hit(det[h], U[h], V[h], Tn[h])) {
+            float tt = Tn[h] / det[h];
+            if (tt < best_t[2 * q + h]) {
+              best_t[2 * q + h] = tt;
+              best_p[2 * q + h] = uint32_t(j);
+            }
+          }
+        }
+      }
+    }
+  }
+
+#pragma unroll
+  for (int k = 0; k < RPL; ++k) {
+    int64_t r = block_base + int64_t(k) * 256 + threadIdx.x;
+    if (r >= R) continue;
+    t_hit[r] = best_t[k];
+    prim_id[r] = best_p[k];
+    if (uv) {
+      float u = 0.f, v = 0.f;
+      if (best_p[k] != PYQSM_MISS_PRIM) {
+        // Re-evaluate the winner with the same operation sequence.
+        const Tri t = load_tri(tri, int(best_p[k]));
+        RayPair one;
+        const int q = k >> 1, h = k & 1;
+        one.ox = splat(rp[q].ox[h]); one.oy = splat(rp[q].oy[h]); one.oz = splat(rp[q].oz[h]);
+        one.dx = splat(rp[q].dx[h]); one.dy = splat(rp[q].dy[h]); one.dz = splat(rp[q].dz[h]);
+        f2 px, py, pz, det, tvx, tvy, tvz, U, V, Tn;
+        mt_front(one, t, px, py, pz, det, tvx, tvy, tvz, U);
+        mt_back(one, t, tvx, tvy, tvz, V, Tn);
+        u = U[0] / det[0];
+        v = V[0] / det[0];
+      }
+      uv[2 * r] = u;
+      uv[2 * r + 1] = v;
+    }
+  }
+}
+
+// Crossing counts and (optionally) hit records: one ray per lane, all triangles.
+// mode 0: counts only. mode 1: write records at offsets[r] + running index.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_all_hits(const TriRec* __restrict__ tri, int T,
+                                                  const float* __restrict__ rays, int64_t R,
+                                                  int32_t* __restrict__ counts,
+                                                  const int64_t* __restrict__ offsets,
+                                                  int64_t cap, uint32_t* __restrict__ ray_ids,
+                                                  uint32_t* __restrict__ prim_ids,
+                                                  float* __restrict__ ts, float* __restrict__ uv) {
+  int64_t r = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  RayPair rp;
+  float o0 = 0.f, o1 = 0.f, o2 = 0.f, d0 = 0.f, d1 = 0.f, d2 = 0.f;
+  if (r < R) {
+    const float* p = rays + 6 * r;
+    o0 = p[0]; o1 = p[1]; o2 = p[2]; d0 = p[3]; d1 = p[4]; d2 = p[5];
+  }
+  rp.ox = splat(o0); rp.oy = splat(o1); rp.oz = splat(o2);
+  rp.dx = splat(d0); rp.dy = splat(d1); rp.dz = splat(d2);
+  int32_t n = 0;
+  int64_t base = (MODE == 1 && r < R) ? offsets[r] : 0;
+  Tri nxt = load_tri(tri, 0);
+  for (int j = 0; j < T; ++j) {
+    const Tri t = nxt;
+    nxt = load_tri(tri, j + 1 < T ? j + 1 : j);
+    f2 px, py, pz, det, tvx, tvy, tvz, U;
+    mt_front(rp, t, px, py, pz, det, tvx, tvy, tvz, U);
+    const f2 key = alive_key(det, U);
+    bool alive = u_alive(key[0], det[0]);
+    if (__builtin_amdgcn_ballot_w64(alive) != 0) {
+      f2 V, Tn;
+      mt_back(rp, t, tvx, tvy, tvz, V, Tn);
+      if (r < R && is_hit(det[0], U[0], V[0], Tn[0])) {
+        if (MODE == 1) {
+          int64_t w = base + n;
+          if (w < cap) {
+            ray_ids[w] = uint32_t(r);
+            prim_ids[w] = uint32_t(j);
+            ts[w] = Tn[0] / det[0];
+            uv[2 * w] = U[0] / det[0];
+            uv[2 * w + 1] = V[0] / det[0];
+          }
+        }
+        ++n;
+      }
+    }
+  }
+  if (MODE == 0 && r < R) counts[r] = n;
+}
+
+__global__ void k_scan_counts_serial(const int32_t* __restrict__ counts, int64_t R,
+                                     int64_t* __restrict__ offsets, int64_t* __restrict__ total) {
+  // Single-thread-block exclusive scan in 64-bit; R is small for this path
+  // (list_intersections is used with sparse ray grids).
+  __shared__ int64_t carry;
+  __shared__ int64_t buf[1024];
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < R; base += 1024) {
+    int64_t i = base + threadIdx.x;
+    int64_t v = i < R ? counts[i] : 0;
+    buf[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      int64_t add = threadIdx.x >= off ? buf[threadIdx.x - off] : 0;
+      __syncthreads();
+      buf[threadIdx.x] += add;
+      __syncthreads();
+    }
+    if (i < R) offsets[i] = carry + buf[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += buf[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total = carry;
+}
+
+__global__ void k_fill_miss(int64_t R, float* __restrict__ t_hit, uint32_t* __restrict__ prim,
+                            float* __restrict__ uv) {
+  int64_t r = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+  if (r >= R) return;
+  t_hit[r] = __builtin_inff();
+  prim[r] = PYQSM_MISS_PRIM;
+  if (uv) uv[2 * r] = uv[2 * r + 1] = 0.f;
+}
+
+static int launch_cast(Ctx* c, const TriRec* tri, int64_t T, const float* rays, int64_t R,
+                       float* t_hit, uint32_t* prim, float* uv) {
+  if (R == 0) return 0;
+  if (T == 0) {  // empty mesh: every ray misses
+    hipLaunchKernelGGL(k_fill_miss, dim3(ceil_div(R, 256)), dim3(256), 0, c->stream, R, t_hit, prim,
+                       uv);
+    PQ_HIP(hipGetLastError());
+    return 0;
+  }
+  ProfScope ps(c, "cast_rays");
+  // Rays per lane: 8 when there are enough rays to fill the chip that way,
+  // fewer for small batches so that more waves exist.
+  const int64_t waves_needed = int64_t(c->cu_count) * 8;
+  if (R >= waves_needed * 64 * 8) {
+    hipLaunchKernelGGL(k_cast_rays<4>, dim3(ceil_div(R, 256 * 8)), dim3(256), 0, c->stream, tri,
+                       int(T), rays, R, t_hit, prim, uv);
+  } else if (R >= waves_needed * 64 * 4) {
+    hipLaunchKernelGGL(k_cast_rays<2>, dim3(ceil_div(R, 256 * 4)), dim3(256), 0, c->stream, tri,
+                       int(T), rays, R, t_hit, prim, uv);
+  } else {
+    hipLaunchKernelGGL(k_cast_rays<1>, dim3(ceil_div(R, 256 * 2)), dim3(256), 0, c->stream, tri,
+                       int(T), rays, R, t_hit, prim, uv);
+  }
+  PQ_HIP(hipGetLastError());
+  return 0;
+}
+
+static int expand(Ctx* c, const float* verts, int64_t V, const int32_t* tris, int64_t T,
+                  TriRec* out) {
+  if (T == 0) return 0;
+  int* bad = nullptr;
+  PQ_TRY(c->arena.get(1, &bad));
+  PQ_HIP(hipMemsetAsync(bad, 0, sizeof(int), c->stream));
+  hipLaunchKernelGGL(k_expand_tris, dim3(ceil_div(T, 256)), dim3(256), 0, c->stream, verts, V, tris,
+                     T, out, bad);
+  PQ_HIP(hipGetLastError());
+  int h = 0;
+  PQ_HIP(hipMemcpyAsync(&h, bad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  PQ_HIP(hipStreamSynchronize(c->stream));
+  if (h) return fail(PYQSM_EINVAL, "triangle index outside [0, V)");
+  return 0;
+}
+
+static int check_sizes(int64_t V, int64_t T, int64_t R) {
+  if (V < 0 || T < 0 || R < 0) return fail(PYQSM_EINVAL, "negative size");
+  if (T > 0x7FFFFFF0LL) return fail(PYQSM_ERANGE, "more than 2^31 triangles");
+  if (R > 0xFFFFFFF0LL) return fail(PYQSM_ERANGE, "more than 2^32 rays per call");
+  return 0;
+}
+
+}  // namespace pyqsm
+
+using namespace pyqsm;
+
+extern "C" {
+
+int pyqsm_expand_tris_dev(const float* verts_dev, int64_t V, const int32_t* tris_dev, int64_t T,
+                          float* tri12_dev, int32_t device) {
+  PQ_TRY(check_sizes(V, T, 0));
+  if (T > 0 && (!verts_dev || !tris_dev || !tri12_dev))
+    return fail(PYQSM_EINVAL, "pyqsm_expand_tris_dev: NULL pointer");
+  Ctx* c = ctx_for(device);
+  if (!c) return PYQSM_ENODEV;
+  std::lock_guard<std::mutex> lk(c->mu);
+  c->arena.reset();
+  return expand(c, verts_dev, V, tris_dev, T, reinterpret_cast<TriRec*>(tri12_dev));
+}
+
+int pyqsm_cast_rays_dev(const float* tri12_dev, int64_t T, const float* rays_dev, int64_t R,
+                        float* t_hit_dev, uint32_t* prim_id_dev, float* uv_dev, int32_t device) {
+  PQ_TRY(check_sizes(0, T, R));
+  if (R > 0 && (!rays_dev || !t_hit_dev || !prim_id_dev || (T > 0 && !tri12_dev)))
+    return fail(PYQSM_EINVAL, "pyqsm_cast_rays_dev: NULL pointer");
+  Ctx* c = ctx_for(device);
+  if (!c) return PYQSM_ENODEV;
+  std::lock_guard<std::mutex> lk(c->mu);
+  return launch_cast(c, reinterpret_cast<const TriRec*>(tri12_dev), T, rays_dev, R, t_hit_dev,
+                     prim_id_dev, uv_dev);
+}
+
+int pyqsm_cast_rays(const float* verts, int64_t V, const int32_t* tris, int64_t T,
+                    const float* rays, int64_t R, float* t_hit, uint32_t* prim_id, float* uv,
+                    int32_t device) {
+  PQ_TRY(check_sizes(V, T, R));
+  if (R == 0) return 0;
+  if (!rays || !t_hit || !prim_id || (T > 0 && (!verts || !tris)))
+    return fail(PYQSM_EINVAL, "pyqsm_cast_rays: NULL pointer");
+  Ctx* c = ctx_for(device);
+  if (!c) return PYQSM_ENODEV;
+  std::lock_guard<std::mutex> lk(c->mu);
+  c->arena.reset();
+  float *d_verts, *d_rays, *d_t, *d_uv = nullptr;
+  int32_t* d_tris;
+  uint32_t* d_p;
+  TriRec* d_rec;
+  PQ_TRY(c->arena.get(size_t(V) * 3 + 1, &d_verts));
+  PQ_TRY(c->arena.get(size_t(T) * 3 + 1, &d_tris));
+  PQ_TRY(c->arena.get(size_t(T) + 1, &d_rec));
+  PQ_TRY(c->arena.get(size_t(R) * 6, &d_rays));
+  PQ_TRY(c->arena.get(size_t(R), &d_t));
+  PQ_TRY(c->arena.get(size_t(R), &d_p));
+  if (uv) PQ_TRY(c->arena.get(size_t(R) * 2, &d_uv));
+  if (T > 0) {
+    PQ_HIP(hipMemcpyAsync(d_verts, verts, size_t(V) * 12, hipMemcpyHostToDevice, c->stream));
+    PQ_HIP(hipMemcpyAsync(d_tris, tris, size_t(T) * 12, hipMemcpyHostToDevice, c->stream));
+  }
+  PQ_HIP(hipMemcpyAsync(d_rays, rays, size_t(R) * 24, hipMemcpyHostToDevice, c->stream));
+  PQ_TRY(expand(c, d_verts, V, d_tris, T, d_rec));
+  PQ_TRY(launch_cast(c, d_rec, T, d_rays, R, d_t, d_p, d_uv));
+  PQ_HIP(hipMemcpyAsync(t_hit, d_t, size_t(R) * 4, hipMemcpyDeviceToHost, c->stream));
+  PQ_HIP(hipMemcpyAsync(prim_id, d_p, size_t(R) * 4, hipMemcpyDeviceToHost, c->stream));
+  if (uv) PQ_HIP(hipMemcpyAsync(uv, d_uv, size_t(R) * 8, hipMemcpyDeviceToHost, c->stream));
+  PQ_HIP(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int pyqsm_list_intersections(const float* verts, int64_t V, const int32_t* tris, int64_t T,
+                             const float* rays, int64_t R, int32_t* counts, uint32_t* ray_ids,
+                             uint32_t* prim_ids, float* t, float* uv, int64_t hits_cap,
+                             int64_t* n_hits, int32_t device) {
+  PQ_TRY(check_sizes(V, T, R));
+  if (n_hits) *n_hits = 0;
+  if (R == 0) return 0;
+  if (!rays || !counts || (T > 0 && (!verts || !tris)))
+    return fail(PYQSM_EINVAL, "pyqsm_list_intersections: NULL pointer");
+  if (hits_cap > 0 && (!ray_ids || !prim_ids || !t || !uv))
+    return fail(PYQSM_EINVAL, "pyqsm_list_intersections: hits_cap > 0 needs every record array");
+  Ctx* c = ctx_for(device);
+  if (!c) return PYQSM_ENODEV;
+  std::lock_guard<std::mutex> lk(c->mu);
+  c->arena.reset();
+  float *d_verts, *d_rays;
+  int32_t *d_tris, *d_counts;
+  TriRec* d_rec;
+  int64_t *d_off, *d_total;
+  PQ_TRY(c->arena.get(size_t(V) * 3 + 1, &d_verts));
+  PQ_TRY(c->arena.get(size_t(T) * 3 + 1, &d_tris));
+  PQ_TRY(c->arena.get(size_t(T) + 1, &d_rec));
+  PQ_TRY(c->arena.get(size_t(R) * 6, &d_rays));
+  PQ_TRY(c->arena.get(size_t(R), &d_counts));
+  PQ_TRY(c->arena.get(size_t(R), &d_off));
+  PQ_TRY(c->arena.get(1, &d_total));
+  if (T > 0) {
+    PQ_HIP(hipMemcpyAsync(d_verts, verts, size_t(V) * 12, hipMemcpyHostToDevice, c->stream));
+    PQ_HIP(hipMemcpyAsync(d_tris, tris, size_t(T) * 12, hipMemcpyHostToDevice, c->stream));
+  }
+  PQ_HIP(hipMemcpyAsync(d_rays, rays, size_t(R) * 24, hipMemcpyHostToDevice, c->stream));
+  PQ_TRY(expand(c, d_verts, V, d_tris, T, d_rec));
+  const dim3 grid(ceil_div(R, 256));
+  if (T == 0) {
+    memset(counts, 0, size_t(R) * 4);
+    return 0;
+  }
+  {
+    ProfScope ps(c, "all_hits");
+    hipLaunchKernelGGL(k_all_hits<0>, grid, dim3(256), 0, c->stream, d_rec, int(T), d_rays, R,
+                       d_counts, nullptr, 0, nullptr, nullptr, nullptr, nullptr);
+    PQ_HIP(hipGetLastError());
+  }
+  PQ_HIP(hipMemcpyAsync(counts, d_counts, size_t(R) * 4, hipMemcpyDeviceToHost, c->stream));
+  hipLaunchKernelGGL(k_scan_counts_serial, dim3(1), dim3(1024), 0, c->stream, d_counts, R, d_off,
+                     d_total);
+  PQ_HIP(hipGetLastError());
+  int64_t total = 0;
+  PQ_HIP(hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, c->stream));
+  PQ_HIP(hipStreamSynchronize(c->stream));
+  if (n_hits) *n_hits = total;
+  if (hits_cap > 0 && total > 0) {
+    const int64_t cap = hits_cap < total ? hits_cap : total;
+    uint32_t *d_r, *d_p;
+    float *d_t, *d_uv;
+    PQ_TRY(c->arena.get(size_t(cap), &d_r));
+    PQ_TRY(c->arena.get(size_t(cap), &d_p));
+    PQ_TRY(c->arena.get(size_t(cap), &d_t));
+    PQ_TRY(c->arena.get(size_t(cap) * 2, &d_uv));
+    hipLaunchKernelGGL(k_all_hits<1>, grid, dim3(256), 0, c->stream, d_rec, int(T), d_rays, R,
+                       nullptr, d_off, cap, d_r, d_p, d_t, d_uv);
+    PQ_HIP(hipGetLastError());
+    PQ_HIP(hipMemcpyAsync(ray_ids, d_r, size_t(cap) * 4, hipMemcpyDeviceToHost, c->stream));
+    PQ_HIP(hipMemcpyAsync(prim_ids, d_p, size_t(cap) * 4, hipMemcpyDeviceToHost, c->stream));
+    PQ_HIP(hipMemcpyAsync(t, d_t, size_t(cap) * 4, hipMemcpyDeviceToHost, c->stream));
+    PQ_HIP(hipMemcpyAsync(uv, d_uv, size_t(cap) * 8, hipMemcpyDeviceToHost, c->stream));
+    PQ_HIP(hipStreamSynchronize(c->stream));
+  }
+  return 0;
+}
+
+}  // extern "C"
