@@ -105,12 +105,8 @@ __global__ __launch_bounds__(256) void k_count_occupied(const int32_t* __restric
   if ((threadIdx.x & 63) == 0 && local) atomicAdd(out, local);
 }
 
-int build_grid(Ctx* c, const double* xyz, int64_t n, double min_cell, int64_t max_cells,
-               DevGrid* g) {
-  if (n <= 0) return fail(PYQSM_EINVAL, "build_grid: empty cloud");
-  if (n > 0x7FFFFF00LL) return fail(PYQSM_ERANGE, "more than 2^31 points per call");
-  if (!(min_cell > 0) || !std::isfinite(min_cell))
-    return fail(PYQSM_EINVAL, "cell edge must be positive and finite");
+int cloud_bbox(Ctx* c, const double* xyz, int64_t n, double mn[3], double mx[3]) {
+  if (n <= 0) return fail(PYQSM_EINVAL, "bounding box of an empty cloud");
   unsigned long long* d_box = nullptr;
   PQ_TRY(c->arena.get(6, &d_box));
   unsigned long long init[6] = {~0ull, ~0ull, ~0ull, 0, 0, 0};
@@ -121,12 +117,29 @@ int build_grid(Ctx* c, const double* xyz, int64_t n, double min_cell, int64_t ma
   unsigned long long h_box[6];
   PQ_HIP(hipMemcpyAsync(h_box, d_box, sizeof(h_box), hipMemcpyDeviceToHost, c->stream));
   PQ_HIP(hipStreamSynchronize(c->stream));
-  double mn[3], mx[3];
   for (int a = 0; a < 3; ++a) {
     mn[a] = ord_val(h_box[a]);
     mx[a] = ord_val(h_box[3 + a]);
     if (!std::isfinite(mn[a]) || !std::isfinite(mx[a]))
       return fail(PYQSM_EINVAL, "point coordinates must be finite");
+  }
+  return 0;
+}
+
+int build_grid(Ctx* c, const double* xyz, int64_t n, double min_cell, int64_t max_cells,
+               DevGrid* g, const double* bbox) {
+  if (n <= 0) return fail(PYQSM_EINVAL, "build_grid: empty cloud");
+  if (n > 0x7FFFFF00LL) return fail(PYQSM_ERANGE, "more than 2^31 points per call");
+  if (!(min_cell > 0) || !std::isfinite(min_cell))
+    return fail(PYQSM_EINVAL, "cell edge must be positive and finite");
+  double mn[3], mx[3];
+  if (bbox) {
+    for (int a = 0; a < 3; ++a) {
+      mn[a] = bbox[a];
+      mx[a] = bbox[3 + a];
+    }
+  } else {
+    PQ_TRY(cloud_bbox(c, xyz, n, mn, mx));
   }
   double cell = min_cell;
   int dims[3];

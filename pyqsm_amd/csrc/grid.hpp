@@ -28,8 +28,12 @@ struct DevGrid {
 // `max_cells` cells). All arrays come from the context arena. Synchronises the
 // stream once (bounding box read-back). Fails with PYQSM_EINVAL on non-finite
 // coordinates.
+// `bbox` (min xyz, max xyz), when given, skips the bounding-box pass.
 int build_grid(Ctx* c, const double* xyz, int64_t n, double min_cell, int64_t max_cells,
-               DevGrid* g);
+               DevGrid* g, const double* bbox = nullptr);
+
+// Bounding box of the cloud (one reduction kernel + a 48-byte read-back).
+int cloud_bbox(Ctx* c, const double* xyz, int64_t n, double mn[3], double mx[3]);
 
 // Number of occupied cells (reads back one int; synchronises).
 int count_occupied(Ctx* c, const DevGrid& g, int64_t* occupied);

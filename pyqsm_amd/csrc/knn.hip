@@ -1,0 +1,271 @@
+// knn.hip — exact k nearest neighbours of every point of a cloud on gfx950.
+//
+// Stands in for the neighbour search inside robust_laplacian.point_cloud_laplacian
+// (pyQSM/geometry/skeletonize.py:253-255) and for scipy cKDTree.query
+// (pyQSM/geometry/reconstruction.py:238-240).
+//
+// Method: points are counting-sorted into a uniform cell grid (grid.hip) whose
+// edge is tuned so that an occupied cell holds about k/3 points. One lane per
+// query walks Chebyshev shells of cells around its own cell (each shell row is
+// one contiguous run of the sorted arrays) and keeps the best k candidates in a
+// per-lane LDS column (element j of lane t at [j*T + t]: conflict-free). A
+// query is final once its k-th distance is no larger than the radius the
+// visited cube is known to cover. The few queries that are not final after
+// kMaxRing shells (isolated outliers) are retried on a 4x coarser grid, and so
+// on, until the grid is small enough for the rings to cover it entirely.
+//
+// Distances are squared, fp64, ((dx*dx)+dy*dy)+dz*dz with separately rounded
+// products — the accumulation order of scipy's cKDTree — and candidates are
+// ordered by (d2, original index).
+#include "grid.hpp"
+
+#include <cmath>
+
+namespace pyqsm {
+
+static constexpr int kMaxRing = 3;
+static constexpr int kMaxK = 192;
+
+struct KnnGrid {
+  int nx, ny, nz;
+  double cell;
+};
+
+__device__ __forceinline__ double sqdist3(double ax, double ay, double az, double bx, double by,
+                                          double bz) {
+  double t0 = ax - bx, t1 = ay - by, t2 = az - bz;
+  double d = t0 * t0;
+  d = d + t1 * t1;
+  d = d + t2 * t2;
+  return d;
+}
+
+// T = threads per block (LDS holds T columns of k (d2, id) pairs).
+template <int T>
+__global__ __launch_bounds__(T) void k_knn(int n_query, const int32_t* __restrict__ query_list,
+                                           const int32_t* __restrict__ pos_of /*orig->sorted*/,
+                                           KnnGrid g, const int32_t* __restrict__ start,
+                                           const int32_t* __restrict__ order,
+                                           const int32_t* __restrict__ cell_of,
+                                           const double* __restrict__ sx,
+                                           const double* __restrict__ sy,
+                                           const double* __restrict__ sz, int k,
+                                           int exclude_self, int n_total, int last_level,
+                                           int32_t* __restrict__ out_idx,
+                                           double* __restrict__ out_d2,
+                                           int32_t* __restrict__ fail_list,
+                                           int32_t* __restrict__ fail_count) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  double* bd = reinterpret_cast<double*>(smem);              // [k][T]
+  int32_t* bi = reinterpret_cast<int32_t*>(bd + size_t(k) * T);  // [k][T]
+  const int t = threadIdx.x;
+  const int qi = blockIdx.x * T + t;
+  if (qi >= n_query) return;
+  // sorted position of this query
+  const int p = query_list ? pos_of[query_list[qi]] : qi;
+  const int self = order[p];
+  const double x = sx[p], y = sy[p], z = sz[p];
+  const int c = cell_of[p];
+  const int cx = c % g.nx, cy = (c / g.nx) % g.ny, cz = c / (g.nx * g.ny);
+  int have = 0;
+  bool done = false;
+  const int rmax_grid = max(g.nx, max(g.ny, g.nz));
+  for (int r = 0; r <= kMaxRing && !done; ++r) {
+    for (int dz = -r; dz <= r; ++dz) {
+      const int zz = cz + dz;
+      if (zz < 0 || zz >= g.nz) continue;
+      for (int dy = -r; dy <= r; ++dy) {
+        const int yy = cy + dy;
+        if (yy < 0 || yy >= g.ny) continue;
+        const int row = (zz * g.ny + yy) * g.nx;
+        const bool full = (dz == -r || dz == r || dy == -r || dy == r);
+        // full shell row: [cx-r, cx+r]; otherwise the two end cells only
+        const int nseg = full ? 1 : (r > 0 ? 2 : 1);
+        for (int s = 0; s < nseg; ++s) {
+          int x0, x1;
+          if (full) {
+            x0 = cx - r;
+            x1 = cx + r;
+          } else {
+            x0 = x1 = s == 0 ? cx - r : cx + r;
+          }
+          x0 = x0 < 0 ? 0 : x0;
+          x1 = x1 >= g.nx ? g.nx - 1 : x1;
+          if (x0 > x1) continue;
+          const int qb = start[row + x0], qe = start[row + x1 + 1];
+          for (int q = qb; q < qe; ++q) {
+            if (exclude_self && q == p) continue;
+            const double d = sqdist3(x, y, z, sx[q], sy[q], sz[q]);
+            const int id = order[q];
+            if (have == k) {
+              const double wd = bd[(k - 1) * T + t];
+              if (d > wd || (d == wd && id > bi[(k - 1) * T + t])) continue;
+            }
+            int j = have < k ? have : k - 1;
+            while (j > 0) {
+              const double pd = bd[(j - 1) * T + t];
+              const int pi = bi[(j - 1) * T + t];
+              if (pd < d || (pd == d && pi < id)) break;
+              bd[j * T + t] = pd;
+              bi[j * T + t] = pi;
+              --j;
+            }
+            bd[j * T + t] = d;
+            bi[j * T + t] = id;
+            if (have < k) ++have;
+          }
+        }
+      }
+    }
+    // everything outside the visited cube is at least r cells away
+    const double safe = double(r) * g.cell * 0.999999;
+    if (have == k && bd[(k - 1) * T + t] <= safe * safe) done = true;
+    if (r >= rmax_grid) done = true;  // the cube already covers the whole grid
+  }
+  if (!done && !last_level) {
+    fail_list[atomicAdd(fail_count, 1)] = self;
+    return;
+  }
+  for (int j = 0; j < k; ++j) {
+    out_idx[size_t(self) * k + j] = j < have ? bi[j * T + t] : n_total;
+    out_d2[size_t(self) * k + j] = j < have ? bd[j * T + t] : __builtin_inf();
+  }
+}
+
+__global__ __launch_bounds__(256) void k_invert_order(int n, const int32_t* __restrict__ order,
+                                                      int32_t* __restrict__ pos_of) {
+  int p = blockIdx.x * 256 + threadIdx.x;
+  if (p < n) pos_of[order[p]] = p;
+}
+
+template <int T>
+static int launch_knn(Ctx* c, int n_query, const int32_t* list, const int32_t* pos_of,
+                      const DevGrid& g, int k, int excl, int n_total, int last, int32_t* idx,
+                      double* d2, int32_t* fail_list, int32_t* fail_count) {
+  const size_t smem = size_t(k) * T * 12;
+  static bool attr_set = false;
+  if (!attr_set) {
+    PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_knn<T>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  KnnGrid kg{g.nx, g.ny, g.nz, g.cell};
+  hipLaunchKernelGGL(k_knn<T>, dim3(ceil_div(n_query, T)), dim3(T), smem, c->stream, n_query, list,
+                     pos_of, kg, g.start, g.order, g.cell_of, g.sx, g.sy, g.sz, k, excl, n_total,
+                     last, idx, d2, fail_list, fail_count);
+  PQ_HIP(hipGetLastError());
+  return 0;
+}
+
+int knn_device(Ctx* c, const double* xyz, int64_t n, int32_t k, int32_t exclude_self,
+               int32_t* idx, double* d2) {
+  if (k <= 0 || k > kMaxK) return fail(PYQSM_ERANGE, "k must be in [1, %d]", kMaxK);
+  if (n == 0) return 0;
+  const int N = int(n);
+  // ---- level-0 cell edge: aim at ~k/3 points per occupied cell -----------
+  DevGrid g;
+  const int64_t max_cells = int64_t(1) << 27;
+  double cell = 0.0;
+  {
+    ProfScope ps(c, "knn_bin");
+    double box[6];
+    PQ_TRY(cloud_bbox(c, xyz, n, box, box + 3));
+    double ext = std::max(box[3] - box[0], std::max(box[4] - box[1], box[5] - box[2]));
+    if (!(ext > 0)) ext = 1.0;
+    cell = ext / 1024.0;
+    const double target = std::max(2.0, double(k) / 3.0);
+    for (int it = 0; it < 4; ++it) {
+      PQ_TRY(build_grid(c, xyz, n, cell, max_cells, &g, box));
+      int64_t occ = 0;
+      PQ_TRY(count_occupied(c, g, &occ));
+      const double per = double(n) / double(occ > 0 ? occ : 1);
+      if (per >= 0.6 * target && per <= 1.7 * target) break;
+      if (per < target && g.nx <= 3 && g.ny <= 3 && g.nz <= 3) break;  // cannot coarsen further
+      double f = std::sqrt(target / per);  // surface-like data: count ~ edge^2
+      f = std::min(4.0, std::max(0.25, f));
+      if (f < 1.0 && g.cell > cell * 1.0000001) break;  // grid already at its size cap
+      cell = g.cell * f;
+    }
+  }
+  int32_t *pos_of = nullptr, *fail_a, *fail_b, *fail_count;
+  PQ_TRY(c->arena.get(size_t(n), &fail_a));
+  PQ_TRY(c->arena.get(size_t(n), &fail_b));
+  PQ_TRY(c->arena.get(1, &fail_count));
+  int n_query = N;
+  const int32_t* list = nullptr;
+  for (int level = 0;; ++level) {
+    const int last = (g.nx - 2 <= kMaxRing && g.ny - 2 <= kMaxRing && g.nz - 2 <= kMaxRing) ? 1 : 0;
+    PQ_HIP(hipMemsetAsync(fail_count, 0, 4, c->stream));
+    {
+      ProfScope ps(c, level == 0 ? "knn_search" : "knn_retry");
+      int32_t* fl = (level & 1) ? fail_b : fail_a;
+      if (k <= 48)
+        PQ_TRY(launch_knn<256>(c, n_query, list, pos_of, g, k, exclude_self, N, last, idx, d2, fl,
+                               fail_count));
+      else if (k <= 96)
+        PQ_TRY(launch_knn<128>(c, n_query, list, pos_of, g, k, exclude_self, N, last, idx, d2, fl,
+                               fail_count));
+      else
+        PQ_TRY(launch_knn<64>(c, n_query, list, pos_of, g, k, exclude_self, N, last, idx, d2, fl,
+                              fail_count));
+    }
+    if (last) break;
+    int32_t nf = 0;
+    PQ_HIP(hipMemcpyAsync(&nf, fail_count, 4, hipMemcpyDeviceToHost, c->stream));
+    PQ_HIP(hipStreamSynchronize(c->stream));
+    if (nf == 0) break;
+    // retry the stragglers on a 4x coarser grid
+    ProfScope ps(c, "knn_bin");
+    list = (level & 1) ? fail_b : fail_a;
+    n_query = nf;
+    PQ_TRY(build_grid(c, xyz, n, g.cell * 4.0, max_cells, &g));
+    if (!pos_of) PQ_TRY(c->arena.get(size_t(n), &pos_of));
+    hipLaunchKernelGGL(k_invert_order, dim3(ceil_div(n, 256)), dim3(256), 0, c->stream, N, g.order,
+                       pos_of);
+    PQ_HIP(hipGetLastError());
+  }
+  return 0;
+}
+
+}  // namespace pyqsm
+
+using namespace pyqsm;
+
+extern "C" {
+
+int pyqsm_knn_dev(const double* xyz_dev, int64_t n, int32_t k, int32_t exclude_self,
+                  int32_t* idx_dev, double* d2_dev, int32_t device) {
+  if (n < 0) return fail(PYQSM_EINVAL, "negative size");
+  if (n > 0 && (!xyz_dev || !idx_dev || !d2_dev))
+    return fail(PYQSM_EINVAL, "pyqsm_knn_dev: NULL pointer");
+  Ctx* c = ctx_for(device);
+  if (!c) return PYQSM_ENODEV;
+  std::lock_guard<std::mutex> lk(c->mu);
+  c->arena.reset();
+  ProfScope ps(c, "knn_total");
+  return knn_device(c, xyz_dev, n, k, exclude_self, idx_dev, d2_dev);
+}
+
+int pyqsm_knn(const double* xyz, int64_t n, int32_t k, int32_t exclude_self, int32_t* idx,
+              double* d2, int32_t device) {
+  if (n < 0) return fail(PYQSM_EINVAL, "negative size");
+  if (n == 0) return 0;
+  if (!xyz || !idx || !d2) return fail(PYQSM_EINVAL, "pyqsm_knn: NULL pointer");
+  Ctx* c = ctx_for(device);
+  if (!c) return PYQSM_ENODEV;
+  std::lock_guard<std::mutex> lk(c->mu);
+  c->arena.reset();
+  double *d_xyz, *d_d2;
+  int32_t* d_idx;
+  PQ_TRY(c->arena.get(size_t(n) * 3, &d_xyz));
+  PQ_TRY(c->arena.get(size_t(n) * size_t(k > 0 ? k : 1), &d_idx));
+  PQ_TRY(c->arena.get(size_t(n) * size_t(k > 0 ? k : 1), &d_d2));
+  PQ_HIP(hipMemcpyAsync(d_xyz, xyz, size_t(n) * 24, hipMemcpyHostToDevice, c->stream));
+  PQ_TRY(knn_device(c, d_xyz, n, k, exclude_self, d_idx, d_d2));
+  PQ_HIP(hipMemcpyAsync(idx, d_idx, size_t(n) * k * 4, hipMemcpyDeviceToHost, c->stream));
+  PQ_HIP(hipMemcpyAsync(d2, d_d2, size_t(n) * k * 8, hipMemcpyDeviceToHost, c->stream));
+  PQ_HIP(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+}  // extern "C"

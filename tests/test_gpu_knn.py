@@ -1,0 +1,56 @@
+"""HIP kNN vs scipy cKDTree fixtures and the CPU oracle (squared distances bit-exact;
+indices exact wherever distances are distinct)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from pyqsm_amd import hip, synth
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "knn_*.npz"))))
+def test_against_ckdtree_fixture(gpu, path):
+    g = np.load(path)
+    idx, d2 = hip.knn(g["points"], int(g["k"]), True, device=gpu)
+    assert np.array_equal(np.sqrt(d2), g["dist"])      # cKDTree returns sqrt of the same sum
+    distinct = np.ones_like(idx, dtype=bool)
+    distinct[:, 1:] &= d2[:, 1:] != d2[:, :-1]
+    distinct[:, :-1] &= d2[:, :-1] != d2[:, 1:]
+    assert np.array_equal(idx[distinct], g["idx"][distinct])
+
+
+@pytest.mark.parametrize("n,k,excl", [(50_000, 20, True), (20_000, 8, False), (3000, 64, True),
+                                      (700, 150, True)])
+def test_against_oracle(gpu, n, k, excl):
+    P = synth.forest(n, seed=2)
+    idx, d2 = hip.knn(P, k, excl, device=gpu)
+    idx0, d20 = oracle.knn(P, k, excl)
+    assert np.array_equal(d2, d20)
+    assert np.array_equal(idx, idx0)                   # ties broken by index on both sides
+
+
+def test_small_and_degenerate(gpu):
+    P = np.array([[0.0, 0, 0], [1, 0, 0], [0, 2, 0]])
+    idx, d2 = hip.knn(P, 5, True, device=gpu)          # fewer points than k: padded
+    assert list(idx[0]) == [1, 2, 3, 3, 3]
+    assert list(d2[0][:2]) == [1.0, 4.0] and np.all(np.isinf(d2[0][2:]))
+    same = np.zeros((40, 3)) + 0.5                     # all points identical
+    idx, d2 = hip.knn(same, 3, True, device=gpu)
+    assert np.all(d2 == 0)
+    assert list(idx[0]) == [1, 2, 3] and list(idx[39]) == [0, 1, 2]
+    idx, d2 = hip.knn(np.zeros((0, 3)), 4, True, device=gpu)
+    assert idx.shape == (0, 4)
+
+
+def test_outliers_far_from_everything(gpu):
+    rng = np.random.default_rng(5)
+    P = np.concatenate([rng.normal(0, 0.01, (5000, 3)), rng.uniform(-500, 500, (30, 3))])
+    P = P.astype(np.float32).astype(np.float64)
+    idx, d2 = hip.knn(P, 10, True, device=gpu)
+    idx0, d20 = oracle.knn(P, 10, True)
+    assert np.array_equal(d2, d20) and np.array_equal(idx, idx0)

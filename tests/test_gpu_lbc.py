@@ -1,0 +1,66 @@
+"""HIP contraction solve vs SciPy spsolve fixtures (skeletonize.py:148-180);
+tolerance 1e-5 relative on vertex positions (BASELINE.json north_star)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+from scipy.sparse import csr_matrix
+
+import oracle
+from pyqsm_amd import hip
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+RTOL = 1e-5
+
+
+def _load(path):
+    g = np.load(path)
+    n = len(g["points"])
+    L = csr_matrix((g["data"], g["indices"], g["indptr"]), shape=(n, n))
+    return g, L
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "lbc_*.npz"))))
+def test_solve_matches_spsolve_fixture(gpu, path):
+    g, L = _load(path)
+    x, iters, resid, ok = hip.lbc_solve(L, g["wl"], g["wh"], g["points"], rtol=1e-12,
+                                        max_it=20000, device=gpu)
+    assert ok, (iters, resid)
+    sol = g["solution"]
+    scale = np.abs(sol).max()
+    assert np.abs(x - sol).max() <= RTOL * scale
+    # and the oracle restatement run live agrees with its own fixture
+    live = oracle.least_squares_sparse(g["points"], L, g["wl"], g["wh"])
+    assert np.abs(live - sol).max() <= 1e-9 * scale
+
+
+def test_spmv3_matches_scipy(gpu):
+    g, L = _load(sorted(glob.glob(os.path.join(GOLD, "lbc_*.npz")))[0])
+    x = np.random.default_rng(0).normal(size=g["points"].shape)
+    y = hip.spmv3(L, x, device=gpu)
+    ref = L @ x
+    assert np.abs(y - ref).max() <= 1e-12 * np.abs(ref).max()
+
+
+def test_clamp_matches_reference_loop(gpu):
+    rng = np.random.default_rng(1)
+    pts = rng.normal(0, 2, (1000, 3))
+    lo, hi = np.array([-1.0, -0.5, 0.0]), np.array([1.0, 0.5, 3.0])
+    want = pts.copy()
+    for p in want:                                     # skeletonize.py:291-296
+        for i in range(3):
+            if p[i] < lo[i]:
+                p[i] = lo[i]
+            if p[i] > hi[i]:
+                p[i] = hi[i]
+    got = hip.clamp(pts.copy(), lo, hi, device=gpu)
+    assert np.array_equal(got, want)
+
+
+def test_max_it_reports_no_convergence(gpu):
+    g, L = _load(sorted(glob.glob(os.path.join(GOLD, "lbc_*.npz")))[1])
+    x, iters, resid, ok = hip.lbc_solve(L, g["wl"], g["wh"], g["points"], rtol=1e-14, max_it=25,
+                                        device=gpu)
+    assert not ok and iters == 25 and np.all(np.isfinite(x))
