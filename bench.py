@@ -1,0 +1,264 @@
+#!/usr/bin/env python3
+"""Benchmark of the pyQSM hot path on MI355X (contract: see the task brief).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Primary metric (BASELINE.json): Mpoints/s of DBSCAN on the 1 M-point synthetic
+forest (eps = 0.1, min_neighbors = 10), inputs resident in HBM, one step = one
+full clustering (binning + core flags + union-find + labels). DBSCAN does not
+shard: at N > 1 every rank clusters its own forest (replicas, weak scaling) and
+`value` = all points of all ranks / max-over-ranks time.
+
+Secondary sections on the same JSON line:
+  ray_sweep   500 k-triangle canopy x R sun rays, Mray-tri/s (= R*T/t); rays are
+              sharded over the ranks, the mesh is broadcast and the per-shard
+              results all-gathered with RCCL (strong scaling, R fixed)
+  knn         k = 20 neighbours on the same cloud
+  roofline    dominant kernel of the primary path, HIP-event timed live
+  cpu_baseline  scikit-learn DBSCAN (the reference's own call, fit.py:223) on the
+              host cores of this box, rank 0, N = 1 only
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP32_PEAK_TFLOPS = 157.3     # vector fp32
+FP64_PEAK_TFLOPS = 78.6      # vector fp64
+# SURVEY.md §8 (d-roofline): algorithmic HBM bytes per point of the binned
+# eps-neighbour kernels, and flop per ray-triangle test
+DBSCAN_BYTES_PER_POINT = 341.0
+MT_FLOP_PER_TEST = 45.0      # full Moller-Trumbore test
+MT_FLOP_FRONT = 24.0         # what every test executes here: p (9), det (5), tv (3), U (5), key (2)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--points", type=int, default=1_000_000)
+    ap.add_argument("--tris", type=int, default=500_000)
+    ap.add_argument("--rays", type=int, default=10_000_000)
+    ap.add_argument("--ray-steps", type=int, default=2)
+    ap.add_argument("--no-rays", action="store_true")
+    ap.add_argument("--no-knn", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    dist = torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from pyqsm_amd import _lib, hip, synth
+    from pyqsm_amd.parallel import shard_bounds, shard_sizes
+    dev = local_rank
+    _lib.require_gpu(dev)
+
+    def barrier():
+        hip.sync(dev)
+        if dist is not None:
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    def max_over_ranks(x: float) -> float:
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # ------------------------------------------------------------- DBSCAN (primary)
+    n = args.points
+    pts = synth.forest(n, seed=1000 * rank)          # every rank its own forest
+    d_xyz = hip.DeviceBuffer.from_array(pts, dev)
+    d_lab = hip.DeviceBuffer(n * 8, dev)
+    d_core = hip.DeviceBuffer(n, dev)
+    eps, min_pts = 0.1, 10
+    for _ in range(args.warmup):
+        hip.dbscan_dev(d_xyz.ptr, n, eps, min_pts, d_lab.ptr, d_core.ptr, dev)
+    hip.prof_enable(True, dev)
+    hip.prof_reset(dev)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        hip.dbscan_dev(d_xyz.ptr, n, eps, min_pts, d_lab.ptr, d_core.ptr, dev)
+    barrier()
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+    kernels = {}
+    for name in ("dbscan_bin", "dbscan_core", "dbscan_union", "dbscan_label", "dbscan_total"):
+        ms, cnt = hip.prof_get(name, dev)
+        kernels[name] = {"avg_ms": ms / max(cnt, 1), "launches": cnt}
+    hip.prof_enable(False, dev)
+    labels = d_lab.download((n,), np.int64)
+    n_clusters = int(labels.max() + 1)
+    value = world * n * args.steps / elapsed / 1e6
+    dom = max(("dbscan_bin", "dbscan_core", "dbscan_union", "dbscan_label"),
+              key=lambda k: kernels[k]["avg_ms"])
+    dom_ms = kernels[dom]["avg_ms"]
+    achieved = DBSCAN_BYTES_PER_POINT * n / (dom_ms * 1e-3) / 1e9
+    roofline = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "avg_launch_ms": dom_ms,
+                "note": "algorithmic bytes = 341 B/point (SURVEY.md §8d) x points per launch; "
+                        "the neighbour kernels are FP64-VALU/latency bound, not HBM bound"}
+
+    out = {
+        "metric": "Mpoints/s DBSCAN (1M-pt synthetic forest, eps=0.1, min_neighbors=10)",
+        "value": value, "unit": "Mpoints/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": f"{n}-point synthetic tree cloud (configs[1]), DBSCAN eps=0.1 "
+                               f"min_neighbors=10, {n_clusters} clusters; replicas at N>1",
+                   "points_per_gpu": n, "parallelism": f"replicas x{world}"},
+        "roofline": roofline, "kernels": kernels,
+    }
+
+    # ------------------------------------------------------------- kNN (same cloud)
+    if not args.no_knn:
+        k = 20
+        d_idx = hip.DeviceBuffer(n * k * 4, dev)
+        d_d2 = hip.DeviceBuffer(n * k * 8, dev)
+        hip.knn_dev(d_xyz.ptr, n, k, True, d_idx.ptr, d_d2.ptr, dev)
+        barrier()
+        reps = max(1, min(args.steps, 5))
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            hip.knn_dev(d_xyz.ptr, n, k, True, d_idx.ptr, d_d2.ptr, dev)
+        barrier()
+        dt = max_over_ranks(time.perf_counter() - t0)
+        out["knn"] = {"k": k, "points_per_gpu": n, "steps": reps, "ms_per_step": dt / reps * 1e3,
+                      "value": world * n / (dt / reps) / 1e6, "unit": "Mpoints/s"}
+        d_idx.free()
+        d_d2.free()
+
+    # ------------------------------------------------------------- ray sweep
+    if not args.no_rays:
+        T, R = args.tris, args.rays
+        verts, tris = synth.canopy_mesh(T)           # same seed on every rank
+        if dist is not None:                         # the mesh travels over RCCL
+            tv = torch.from_numpy(verts).cuda() if rank == 0 else torch.empty(
+                verts.shape, dtype=torch.float32, device="cuda")
+            tt = torch.from_numpy(tris).cuda() if rank == 0 else torch.empty(
+                tris.shape, dtype=torch.int32, device="cuda")
+            dist.broadcast(tv, src=0)
+            dist.broadcast(tt, src=0)
+            verts, tris = tv.cpu().numpy(), tt.cpu().numpy()
+        mesh = hip.DeviceMesh(verts, tris, dev)
+        b, e = shard_bounds(R, world, rank)
+        rays = synth.sun_rays(verts, R)[b:e]
+        d_rays = hip.DeviceBuffer.from_array(rays, dev)
+        r_loc = e - b
+        sizes = shard_sizes(R, world)
+        cap = max(sizes)
+        if dist is not None:
+            # results live in torch tensors so that RCCL can gather them in place
+            res = torch.zeros((2, cap), dtype=torch.int32, device="cuda")
+            gathered = [torch.empty_like(res) for _ in range(world)]
+            t_ptr, p_ptr = res[0].data_ptr(), res[1].data_ptr()
+        else:
+            d_t = hip.DeviceBuffer(cap * 4, dev)
+            d_p = hip.DeviceBuffer(cap * 4, dev)
+            t_ptr, p_ptr = d_t.ptr, d_p.ptr
+
+        def sweep():
+            hip.cast_rays_dev(mesh, d_rays.ptr, r_loc, t_ptr, p_ptr)
+            if dist is not None:
+                hip.sync(dev)
+                dist.all_gather(gathered, res)
+
+        sweep()                                       # warm-up
+        hip.prof_enable(True, dev)
+        hip.prof_reset(dev)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.ray_steps):
+            sweep()
+        barrier()
+        dt = max_over_ranks(time.perf_counter() - t0)
+        ms, cnt = hip.prof_get("cast_rays", dev)
+        hip.prof_enable(False, dev)
+        per = dt / args.ray_steps
+        if dist is not None:
+            t_all = np.concatenate([gathered[r][0, : sizes[r]].cpu().numpy().view(np.float32)
+                                    for r in range(world)])
+        else:
+            t_all = d_t.download((r_loc,), np.float32)
+        tests = float(R) * float(T)
+        kern_ms = ms / max(cnt, 1)
+        flops = MT_FLOP_FRONT * float(r_loc) * float(T) / (kern_ms * 1e-3) / 1e12
+        flops_equiv = MT_FLOP_PER_TEST * float(r_loc) * float(T) / (kern_ms * 1e-3) / 1e12
+        out["ray_sweep"] = {
+            "metric": "Mray-tri/s", "value": tests / per / 1e6, "unit": "Mray-tri/s",
+            "rays": R, "tris": T, "steps": args.ray_steps, "ms_per_step": per * 1e3,
+            "scaling": "strong", "hit_fraction": float(np.isfinite(t_all).mean()),
+            "kernel_avg_ms": kern_ms, "dtype": "f32",
+            "roofline": {"bound": "fp32-valu", "achieved": flops, "peak": FP32_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": flops / FP32_PEAK_TFLOPS,
+                         "equivalent_45flop_tflops": flops_equiv,
+                         "note": "executed flops: every test runs the 24-flop front half (p, det, "
+                                 "tv, U, cull key); the 21-flop back half runs only for waves in "
+                                 "which some lane can still hit and is not counted. "
+                                 "equivalent_45flop_tflops prices every test at SURVEY.md §8d's "
+                                 "45 flop and is NOT a utilisation figure"},
+            "algorithmic_hbm_bytes": 24.0 * R + 48.0 * T + 8.0 * R,
+        }
+        if rank == 0 and world == 1 and not args.no_cpu:
+            import oracle
+            sample = 2000
+            sub = synth.sun_rays(verts, R)[:: max(1, R // sample)][:sample]
+            t0 = time.perf_counter()
+            oracle.cast_rays(verts, tris, sub)
+            c = time.perf_counter() - t0
+            out["ray_sweep"]["cpu_baseline"] = {
+                "value": len(sub) * float(T) / c / 1e6, "unit": "Mray-tri/s",
+                "cores": oracle.num_threads(), "kind": "port",
+                "sample": f"{len(sub)} of the {R} rays x {T} triangles, brute-force "
+                          "Moller-Trumbore in C/OpenMP (oracle/pyqsm_oracle.c); NOT Embree "
+                          "(Open3D is not installable here)"}
+
+    # ------------------------------------------------------------- CPU baseline (primary)
+    if rank == 0 and world == 1 and not args.no_cpu:
+        from sklearn.cluster import DBSCAN
+        t0 = time.perf_counter()
+        sk = DBSCAN(eps=eps, min_samples=min_pts).fit(pts)
+        c = time.perf_counter() - t0
+        same = bool(np.array_equal(sk.labels_, labels))
+        out["cpu_baseline"] = {
+            "value": n / c / 1e6, "unit": "Mpoints/s", "cores": 1, "kind": "reference",
+            "sample": f"sklearn.cluster.DBSCAN(eps=0.1, min_samples=10).fit on the same {n} "
+                      "points (the call pyQSM makes at math_utils/fit.py:223), one run, "
+                      f"{os.cpu_count()} host cores visible; labels identical to GPU: {same}"}
+
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,159 @@
+"""DBSCAN clustering and RANSAC circle/cylinder fitting with pyQSM's names and
+signatures (pyQSM/math_utils/fit.py), computed by the HIP kernels.
+
+    cluster_DBSCAN(pts_idxs, points, eps, min_pts)         fit.py:217-250
+    fit_shape_RANSAC(pcd, pts, threshold, lower_bound, ...) fit.py:253-339
+    choose_and_cluster(new_neighbors, main_pts, ...)        fit.py:58-85 (DBSCAN branch)
+    z_align_and_fit(pcd, axis_guess, **kwargs)              fit.py:23-45
+
+plus the aliases BASELINE.json's north_star names: ``dbscan`` and ``fit_cylinder``.
+Differences from the reference, all deliberate: no plotting, no ``breakpoint()``,
+and RANSAC takes optional ``seed`` / ``samples`` / ``max_iterations`` keywords
+(the reference draws its samples from Python's unseeded ``random``).
+"""
+from __future__ import annotations
+
+import random
+
+import numpy as np
+
+try:
+    from .. import hip
+    from ..geometry.cloud import Cylinder, PointCloud, as_points
+    from ..set_config import config, log
+    from .general import get_radius, rotation_matrix_from_arr, unit_vector
+except ImportError:  # imported flat, with pyqsm_amd/ itself on sys.path (pyQSM's layout)
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    from pyqsm_amd import hip
+    from pyqsm_amd.geometry.cloud import Cylinder, PointCloud, as_points
+    from pyqsm_amd.set_config import config, log
+    from pyqsm_amd.math_utils.general import get_radius, rotation_matrix_from_arr, unit_vector
+
+# pyransac3d's default iteration counts (Circle.fit / Cylinder.fit signatures)
+DEFAULT_ITERATIONS = {"circle": 1000, "cylinder": 10000}
+
+
+def dbscan(points, eps=None, min_pts=None, device: int = 0):
+    """labels int64 [n] (-1 = noise) and core mask bool [n] — what
+    ``sklearn.cluster.DBSCAN(eps, min_samples).fit(points)`` exposes as ``labels_``
+    and ``core_sample_indices_`` (fit.py:223-224)."""
+    eps = config["dbscan"]["epsilon"] if eps is None else eps
+    min_pts = config["dbscan"]["min_neighbors"] if min_pts is None else min_pts
+    return hip.dbscan(as_points(points), eps, min_pts, device=device)
+
+
+def cluster_DBSCAN(pts_idxs, points, eps, min_pts):
+    """fit.py:217-250. Returns ``(unique_labels, idxs, noise)``:
+    ``unique_labels`` the set of labels (including -1 when present); ``idxs`` one
+    array of caller indices per non-noise label, in set-iteration order, holding
+    that cluster's CORE samples only; ``noise`` the caller indices with label -1."""
+    labels, core = hip.dbscan(as_points(points), eps, min_pts)
+    pts_idxs = np.asarray(pts_idxs)
+    num_clusters = len(set(labels)) - (1 if -1 in labels else 0)
+    num_noise = int((labels == -1).sum())
+    unique_labels = set(labels)
+    idxs = []
+    noise = []
+    for k in unique_labels:
+        member = labels == k
+        if k == -1:
+            noise = pts_idxs[np.where(member & ~core)]
+        else:
+            idxs.append(pts_idxs[np.where(member & core)])
+    log.info(f"Estimated number of clusters: {num_clusters}")
+    log.info("Estimated number of noise points: %d" % num_noise)
+    return unique_labels, idxs, noise
+
+
+def choose_and_cluster(new_neighbors, main_pts, cluster_type="DBSCAN", debug=False):
+    """fit.py:58-85. Only the DBSCAN branch is on the hot path; ``"kmeans"`` (a
+    SciPy kmeans2 + silhouette heuristic with plotting, fit.py:168-214) is outside
+    the scope of this package and raises."""
+    if cluster_type == "kmeans":
+        raise NotImplementedError("the k-means branch of choose_and_cluster is not part of the "
+                                  "HIP hot path (SURVEY.md §2); pass cluster_type='DBSCAN'")
+    nn_points = np.asarray(main_pts)[new_neighbors]
+    log.info("clustering via DBSCAN")
+    labels, returned_clusters, _noise = cluster_DBSCAN(
+        new_neighbors, nn_points, eps=config["dbscan"]["epsilon"],
+        min_pts=config["dbscan"]["min_neighbors"])
+    return labels, returned_clusters
+
+
+def draw_samples(n_points: int, iterations: int, seed=None) -> np.ndarray:
+    """``iterations`` rows of 3 distinct indices, drawn like pyransac3d does
+    (``random.sample(range(n), 3)`` per iteration) from a private generator."""
+    rng = random.Random(seed)
+    return np.array([rng.sample(range(n_points), 3) for _ in range(iterations)],
+                    dtype=np.int64).reshape(-1, 3)
+
+
+def fit_shape_RANSAC(pcd=None, pts=None, threshold=0.1, lower_bound=None, max_radius=None,
+                     align_to_z=False, shape="circle", seed=None, samples=None,
+                     max_iterations=None, device: int = 0, **kwargs):
+    """fit.py:253-339. Returns ``(cyl_mesh, in_pcd, inliers, fit_radius, axis)`` or
+    five ``None`` when the fit is rejected.
+
+    ``cyl_mesh`` is a :class:`Cylinder` (the reference builds an Open3D mesh of the
+    same centre / radius*1.05 / height / axis). As in the reference, a truthy
+    ``lower_bound`` clamps z IN PLACE in the caller's array (fit.py:265-268)."""
+    if pts is None:
+        pts = np.asarray(pcd.points)
+    if lower_bound:
+        low = pts[:, 2] < lower_bound
+        pts[low, 2] = lower_bound                       # mutates the caller's array, like :266-268
+    if shape not in ("circle", "cylinder"):
+        raise ValueError(f"shape must be 'circle' or 'cylinder', got {shape!r}")
+    if len(pts) < 3:
+        log.info(f"no no fit {shape} found")
+        return None, None, None, None, None
+    _ = get_radius(pts)                                 # :272 (computed, unused by the reference)
+    fit_pts = np.array(pts, dtype=np.float64)           # pts.copy()
+    if shape == "circle":
+        fit_pts[:, 2] = 0.0                             # :274-276
+    if samples is None:
+        iters = max_iterations or DEFAULT_ITERATIONS[shape]
+        samples = draw_samples(len(fit_pts), iters, seed)
+    center, axis, fit_radius, inliers, best = hip.ransac(fit_pts, samples, shape, threshold,
+                                                         device=device)
+    log.info(f"fit_cyl = center: {center}, axis: {axis}, radius: {fit_radius}")
+    if best < 0:                                        # pyransac3d leaves center == [] (:291)
+        log.info(f"no no fit {shape} found")
+        return None, None, None, None, None
+    if max_radius is not None and fit_radius > max_radius:
+        log.info(f"{shape} had radius {fit_radius} but max_radius is {max_radius}")
+        return None, None, None, None, None
+    in_pts = pts[inliers]
+    lowest, highest = in_pts[:, 2].min(), in_pts[:, 2].max()
+    height = highest - lowest
+    test_center = [center[0], center[1], (height / 2) + lowest]
+    if height <= 0:
+        return None, None, None, None, None
+    cyl_mesh = Cylinder(test_center, fit_radius * 1.05, height, axis)   # :321-332
+    in_pcd = None
+    if pcd is not None:
+        in_pcd = (pcd.select_by_index(inliers) if hasattr(pcd, "select_by_index")
+                  else PointCloud(np.asarray(pcd.points)[inliers]))
+    return cyl_mesh, in_pcd, inliers, fit_radius, axis
+
+
+def fit_cylinder(pts, threshold=0.04, lower_bound=None, max_radius=None, shape="circle", **kwargs):
+    """north_star alias: the call fit_cyl_to_cluster makes (qsm_generation.py:149-155)."""
+    return fit_shape_RANSAC(pts=pts, threshold=threshold, lower_bound=lower_bound,
+                            max_radius=max_radius, shape=shape, **kwargs)
+
+
+def z_align_and_fit(pcd, axis_guess, **kwargs):
+    """fit.py:23-45: rotate the cloud so that ``axis_guess`` is +z, fit a circle to
+    its projection. Returns the 5-tuple of :func:`fit_shape_RANSAC`."""
+    R_to_z = rotation_matrix_from_arr(unit_vector(axis_guess), [0, 0, 1])
+    pts = as_points(pcd)
+    center = pts.mean(axis=0)
+    # Open3D's pcd.rotate(R) rotates about the cloud centre: p' = R (p - c) + c
+    rotated = (pts - center) @ np.asarray(R_to_z).T + center
+    mesh, _, inliers, fit_radius, _ax = fit_shape_RANSAC(pcd=PointCloud(rotated), **kwargs)
+    if mesh is None:
+        log.warning("No mesh found")
+    return mesh, _, inliers, fit_radius, _ax

@@ -1,0 +1,115 @@
+"""The reference-named wrappers (pyQSM signatures) on the GPU, against the oracle's
+restatement of the same reference functions."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle
+from pyqsm_amd import synth
+from pyqsm_amd.geometry.point_cloud_processing import cluster_and_get_largest, cluster_plus
+from pyqsm_amd.math_utils import fit
+from pyqsm_amd.viz import ray_casting as rc
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cluster_DBSCAN_matches_reference_postprocessing(gpu):
+    rng = np.random.default_rng(3)
+    P = (rng.uniform(0, 1, (9000, 3)) * [1, 1, 0.15]).astype(np.float32).astype(np.float64)
+    ids = rng.permutation(50_000)[:9000]
+    labels, idxs, noise = fit.cluster_DBSCAN(ids, P, 0.03, 6)
+    labels0, idxs0, noise0 = oracle.cluster_DBSCAN(ids, P, 0.03, 6)
+    assert labels == labels0 and len(idxs) == len(idxs0) > 5
+    for a, b in zip(idxs, idxs0):
+        assert np.array_equal(a, b)
+    assert np.array_equal(noise, noise0)
+
+
+def test_config_1_50k_tree_through_the_wrapper(gpu):
+    """BASELINE.json configs[0]: 50 k-point trunk+branch cloud, eps=0.1, min_neighbors=10."""
+    from pyqsm_amd.set_config import config
+    P = synth.forest(50_000)
+    labels, idxs, noise = fit.cluster_DBSCAN(np.arange(len(P)), P, config["dbscan"]["epsilon"],
+                                             config["dbscan"]["min_neighbors"])
+    labels0, idxs0, noise0 = oracle.cluster_DBSCAN(np.arange(len(P)), P, 0.1, 10)
+    assert labels == labels0 == {0, -1}
+    assert np.array_equal(idxs[0], idxs0[0]) and np.array_equal(noise, noise0)
+
+
+def test_cluster_plus_and_largest(gpu):
+    P = synth.forest(100_000)
+    by_label = cluster_plus(P, eps=0.1, min_points=10, return_pcds=False)
+    lab0, _ = oracle.dbscan(P, 0.1, 10)
+    assert sorted(by_label) == sorted(np.unique(lab0))
+    for k, idx in by_label.items():
+        assert np.array_equal(idx, np.flatnonzero(lab0 == k))
+    clouds = cluster_plus(P, eps=0.1, min_points=10)
+    assert [len(c.points) for c in clouds] == [len(v) for v in by_label.values()]
+    big = cluster_and_get_largest(P, eps=0.1, min_points=10)
+    assert len(big.points) == max(len(v) for v in by_label.values())
+
+
+def test_fit_shape_RANSAC_circle_like_fit_cyl_to_cluster(gpu):
+    pts = synth.ring_cluster(3000, seed=6)
+    before = pts.copy()
+    lb = float(np.min(pts[:, 2])) + 0.1
+    samples = fit.draw_samples(len(pts), 1000, seed=2)
+    mesh, in_pcd, inliers, r, axis = fit.fit_shape_RANSAC(
+        pts=pts, shape="circle", threshold=0.04, lower_bound=lb, max_radius=0.3 * 1.75,
+        samples=samples)
+    assert np.all(pts[:, 2] >= lb) and not np.array_equal(pts, before)   # in-place clamp (:265)
+    flat = pts.copy()
+    flat[:, 2] = 0
+    c0, a0, r0, inl0, _ = oracle.ransac_fit(flat, samples, "circle", 0.04)
+    assert np.array_equal(inliers, inl0) and abs(r - r0) < 1e-9
+    assert abs(mesh.radius - 1.05 * r) < 1e-12 and mesh.height > 0.3 and in_pcd is None
+    assert len(mesh.sample_points_uniformly(500).points) == 500
+    # rejection by max_radius returns five Nones
+    assert fit.fit_shape_RANSAC(pts=pts, shape="circle", threshold=0.04, max_radius=0.01,
+                                samples=samples) == (None,) * 5
+    # seeded default sampling is reproducible
+    a = fit.fit_shape_RANSAC(pts=pts, shape="circle", threshold=0.04, seed=5)
+    b = fit.fit_shape_RANSAC(pts=pts, shape="circle", threshold=0.04, seed=5)
+    assert np.array_equal(a[2], b[2]) and a[3] == b[3]
+
+
+def test_cast_rays_wrapper_pinhole_and_areas(gpu):
+    verts, tris = synth.canopy_mesh(4000, seed=8, side=0.5)
+    out = rc.cast_rays((verts, tris), surf_2d=True)
+    assert out["t_hit"].shape == (950, 1280) and out["hit"].any()
+    t0, p0, _ = oracle.cast_rays(verts, tris, out["rays"].reshape(-1, 6))
+    assert np.array_equal(out["t_hit"].reshape(-1), t0)
+    assert np.array_equal(out["primitive_ids"].reshape(-1), p0)
+    ids = np.unique(p0[np.isfinite(t0)])
+    assert np.array_equal(out["hit_triangles"], ids)
+    assert abs(out["surface_area_3d"] - len(ids) * 0.125) < 1e-3         # 0.5 m leaves: 0.125 m2
+    assert 0 < out["surface_area_2d"] < out["surface_area_3d"]
+
+
+def test_sparse_cast_and_occupancy(gpu):
+    # a closed unit cube
+    v = np.array([[x, y, z] for x in (0, 1) for y in (0, 1) for z in (0, 1)], dtype=np.float32)
+    f = np.array([[0, 1, 3], [0, 3, 2], [4, 6, 7], [4, 7, 5], [0, 4, 5], [0, 5, 1],
+                  [2, 3, 7], [2, 7, 6], [0, 2, 6], [0, 6, 4], [1, 5, 7], [1, 7, 3]], np.int32)
+    q = np.array([[0.5, 0.4, 0.6], [0.2, 0.9, 0.1], [1.5, 0.4, 0.6], [-1, 0.4, 0.6]], np.float32)
+    assert list(rc.get_points_inside_mesh((v, f), q)) == [1.0, 1.0, 0.0, 0.0]
+    segs, pcd = rc.sparse_cast_w_intersections((v, f), num=4)
+    assert segs.shape == (16, 2, 3)
+    zs = np.sort(np.round(pcd.points[:, 2], 5))
+    assert set(zs) <= {0.0, 1.0} and len(zs) >= 8                        # bottom and top faces
+
+
+def test_flat_imports_run_on_the_gpu(gpu):
+    code = ("import numpy as np\n"
+            "from math_utils.fit import cluster_DBSCAN\n"
+            "P = np.random.default_rng(0).normal(size=(2000, 3))\n"
+            "l, i, n = cluster_DBSCAN(np.arange(2000), P, 0.3, 5)\n"
+            "print(len(l) > 0)")
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "pyqsm_amd"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env,
+                       cwd="/tmp")
+    assert r.returncode == 0 and r.stdout.strip() == "True", r.stderr

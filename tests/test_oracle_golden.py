@@ -1,0 +1,111 @@
+"""Pins the CPU oracle to the golden fixtures: outputs of scikit-learn / SciPy (the
+engines the reference calls) and of the reference's own math_utils/general.py."""
+import glob
+import os
+
+import numpy as np
+import pytest
+from scipy.sparse import csr_matrix
+
+import oracle
+from pyqsm_amd.math_utils import general
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "dbscan_*.npz"))))
+def test_dbscan_oracle_equals_sklearn_fixture(path):
+    g = np.load(path)
+    lab, core = oracle.dbscan(g["points"], float(g["eps"]), int(g["min_pts"]))
+    assert np.array_equal(lab, g["labels"])
+    assert np.array_equal(np.flatnonzero(core), g["core"])
+
+
+def test_dbscan_oracle_equals_sklearn_live():
+    from sklearn.cluster import DBSCAN
+    rng = np.random.default_rng(7)
+    P = (rng.uniform(0, 1, (6000, 3)) * [1, 1, 0.1]).astype(np.float32).astype(np.float64)
+    for eps, mp in ((0.02, 4), (0.04, 12)):
+        sk = DBSCAN(eps=eps, min_samples=mp).fit(P)
+        lab, core = oracle.dbscan(P, eps, mp)
+        assert np.array_equal(lab, sk.labels_)
+        assert np.array_equal(np.flatnonzero(core), sk.core_sample_indices_)
+
+
+def test_cluster_DBSCAN_postprocessing_shape():
+    g = np.load(os.path.join(GOLD, "dbscan_blobs3k.npz"))
+    ids = np.arange(len(g["points"]))[::-1].copy()          # caller indices differ from row ids
+    labels, idxs, noise = oracle.cluster_DBSCAN(ids, g["points"], float(g["eps"]),
+                                                int(g["min_pts"]))
+    assert labels == set(g["labels"])
+    core = np.zeros(len(ids), bool)
+    core[g["core"]] = True
+    assert sum(len(i) for i in idxs) == core.sum()          # core samples only (fit.py:243-246)
+    assert len(idxs) == len(labels - {-1})
+    assert set(noise) == set(ids[(g["labels"] == -1)])
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "knn_*.npz"))))
+def test_knn_oracle_equals_ckdtree_fixture(path):
+    g = np.load(path)
+    idx, d2 = oracle.knn(g["points"], int(g["k"]), True)
+    assert np.array_equal(np.sqrt(d2), g["dist"])
+    distinct = np.ones_like(idx, dtype=bool)
+    distinct[:, 1:] &= d2[:, 1:] != d2[:, :-1]
+    distinct[:, :-1] &= d2[:, :-1] != d2[:, 1:]
+    assert np.array_equal(idx[distinct], g["idx"][distinct])
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "lbc_*.npz"))))
+def test_least_squares_oracle_equals_spsolve_fixture(path):
+    g = np.load(path)
+    n = len(g["points"])
+    L = csr_matrix((g["data"], g["indices"], g["indptr"]), shape=(n, n))
+    x = oracle.least_squares_sparse(g["points"], L, g["wl"], g["wh"])
+    assert np.abs(x - g["solution"]).max() <= 1e-9 * np.abs(g["solution"]).max()
+
+
+def test_general_helpers_equal_reference_outputs():
+    g = np.load(os.path.join(GOLD, "general.npz"))
+    P = g["points"]
+    assert np.allclose(general.get_center(P), g["centroid"], rtol=0, atol=1e-15)
+    assert np.allclose(general.get_center(P, "top"), g["center_top"], rtol=0, atol=1e-15)
+    assert np.allclose(general.get_center(P, "bottom"), g["center_bottom"], rtol=0, atol=1e-15)
+    assert abs(general.get_radius(P) - float(g["radius"])) <= 1e-15
+    z = np.array([0.0, 0.0, 1.0])
+    assert np.allclose(general.rotation_matrix_from_arr(g["axis"], z), g["R_to_z"], atol=1e-15)
+    assert np.allclose(general.rotation_matrix_from_arr(z, g["axis"]), g["R_from_z"], atol=1e-15)
+
+
+def test_ray_oracle_known_answers():
+    verts = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], dtype=np.float32)
+    tris = np.array([[0, 1, 2]], dtype=np.int32)
+    rays = np.array([[0.25, 0.25, 1, 0, 0, -1], [0.25, 0.25, 1, 0, 0, -2],
+                     [0.75, 0.75, 1, 0, 0, -1], [0.25, 0.25, 1, 0, 0, 1]], dtype=np.float32)
+    t, p, uv = oracle.cast_rays(verts, tris, rays)
+    assert t[0] == 1.0 and t[1] == 0.5 and np.isinf(t[2]) and np.isinf(t[3])
+    assert p[0] == 0 and p[2] == 0xFFFFFFFF
+    assert np.allclose(uv[0], [0.25, 0.25])
+    lx = oracle.list_intersections(verts, tris, rays)
+    assert list(lx["counts"]) == [1, 1, 0, 0]
+
+
+def test_ransac_oracle_known_circle():
+    ang = np.linspace(0, 2 * np.pi, 100, endpoint=False)
+    pts = np.stack([2 + 0.5 * np.cos(ang), -1 + 0.5 * np.sin(ang), np.zeros_like(ang)], 1)
+    c, a, r, inl, best = oracle.ransac_fit(pts, np.array([[0, 30, 60]]), "circle", 1e-9)
+    assert best == 0 and len(inl) == 100
+    assert np.allclose(c, [2, -1, 0], atol=1e-12) and abs(r - 0.5) < 1e-12
+
+
+def test_numpy_operation_order_assumed_by_the_ransac_kernel():
+    """ransac.hip hard-codes the order NumPy evaluates the distance in."""
+    rng = np.random.default_rng(0)
+    a, b = rng.normal(size=(50000, 3)), rng.normal(size=(50000, 3))
+    s = a * a
+    assert np.array_equal(np.add.reduce(s, axis=1), (s[:, 0] + s[:, 1]) + s[:, 2])
+    assert np.array_equal(np.linalg.norm(a, axis=1), np.sqrt((s[:, 0] + s[:, 1]) + s[:, 2]))
+    c = np.cross(a, b)
+    assert np.array_equal(c[:, 0], a[:, 1] * b[:, 2] - a[:, 2] * b[:, 1])
+    assert np.array_equal(c[:, 1], a[:, 2] * b[:, 0] - a[:, 0] * b[:, 2])
+    assert np.array_equal(c[:, 2], a[:, 0] * b[:, 1] - a[:, 1] * b[:, 0])
