@@ -36,7 +36,8 @@ extern "C" {
 #define PYQSM_ENODEV (-3)   /* no usable GPU / device index out of range         */
 #define PYQSM_ERANGE (-4)   /* input outside what the kernels are built for      */
 #define PYQSM_ENOMEM (-5)   /* device or host allocation failed                  */
-#define PYQSM_ENOCONV (-6)  /* iterative solve hit max_it before reaching rtol   */
+#define PYQSM_ENOCONV (-6)  /* CG stopped (max_it / stagnation) above rtol; best
+                               iterate is still returned                         */
 
 #define PYQSM_MISS_PRIM 0xFFFFFFFFu /* primitive id reported for a ray that hits nothing */
 
@@ -171,8 +172,10 @@ int pyqsm_ransac_count(const double* pts, int64_t n, const double* models, int64
  * gradient over 3 right-hand sides that never forms L'L.
  *   L as CSR (indptr i32 [n+1], indices i32 [nnz], vals f64 [nnz]);
  *   wl, wh, f64 [n]; pts f64 [n,3] (also the start vector); out f64 [n,3]
- *   stops when |r|/|b| <= rtol for every coordinate or after max_it iterations
- *   (then returns PYQSM_ENOCONV with the best iterate in `out`).
+ *   stops when |r|/|b| <= rtol for every coordinate, after max_it iterations, or
+ *   when the residual has stopped improving (attainable accuracy reached); in the
+ *   last two cases returns PYQSM_ENOCONV with the best iterate in `out` and its
+ *   residuals in `resid`.
  */
 int pyqsm_lbc_solve(const int32_t* indptr, const int32_t* indices, const double* vals,
                     int64_t n, const double* wl, const double* wh, const double* pts,

@@ -52,6 +52,11 @@ def _lib():
         lib.orc_list_intersections.restype = i64
         lib.orc_list_intersections.argtypes = [p, i64, p, i64, p, i64, p, p, p, p, p, i64]
         lib.orc_num_threads.restype = ctypes.c_int
+        lib.orc_pc_laplacian.restype = ctypes.c_int
+        lib.orc_pc_laplacian.argtypes = [p, i64, i32, dbl, ctypes.POINTER(i64),
+                                         ctypes.POINTER(p), ctypes.POINTER(p), ctypes.POINTER(p), p]
+        lib.orc_free.restype = None
+        lib.orc_free.argtypes = [p]
         _LIB = lib
     return _LIB
 
@@ -309,3 +314,34 @@ def extract_skeleton(pts, laplacian, allowed_range, max_iter=20, termination_rat
         if iteration >= max_iter:                                                  # :353
             break
     return cur, total, steps
+
+
+# --------------------------------------------------------------------------
+# Point-cloud Laplacian (robust_laplacian.point_cloud_laplacian,
+# pyQSM/geometry/skeletonize.py:253-255) — own restatement, PARITY UNPINNED.
+
+def point_cloud_laplacian(points, n_neighbors=30, mollify_factor=1e-5):
+    """(L scipy CSR [n,n], mass float64 [n]); see pyqsm_oracle.c: orc_pc_laplacian."""
+    from scipy.sparse import csr_matrix
+    pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+    n = pts.shape[0]
+    lib = _lib()
+    nnz = ctypes.c_int64(0)
+    ip, ix, dv = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+    mass = np.zeros(n, dtype=np.float64)
+    rc = lib.orc_pc_laplacian(_ptr(pts), n, int(n_neighbors), float(mollify_factor),
+                              ctypes.byref(nnz), ctypes.byref(ip), ctypes.byref(ix),
+                              ctypes.byref(dv), _ptr(mass))
+    if rc != 0:
+        raise RuntimeError("orc_pc_laplacian failed (k must be in [3, 64])")
+    try:
+        indptr = np.ctypeslib.as_array(ctypes.cast(ip, ctypes.POINTER(ctypes.c_int32)),
+                                       (n + 1,)).copy()
+        indices = np.ctypeslib.as_array(ctypes.cast(ix, ctypes.POINTER(ctypes.c_int32)),
+                                        (nnz.value + 1,))[:nnz.value].copy()
+        data = np.ctypeslib.as_array(ctypes.cast(dv, ctypes.POINTER(ctypes.c_double)),
+                                     (nnz.value + 1,))[:nnz.value].copy()
+    finally:
+        for q in (ip, ix, dv):
+            lib.orc_free(q)
+    return csr_matrix((data, indices, indptr), shape=(n, n)), mass

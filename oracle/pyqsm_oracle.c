@@ -230,17 +230,16 @@ int orc_knn(const double* xyz, int64_t n, int32_t k, int32_t exclude_self, int32
   for (int a = 0; a < 3; ++a)
     if (mx[a] - mn[a] > ext) ext = mx[a] - mn[a];
   if (!(ext > 0)) ext = 1.0;
-  double cell = ext / 512.0;
+  /* start coarse and halve the cell until an occupied cell holds a handful of points */
+  double cell = ext / 16.0;
   grid_t g;
   for (int it = 0;; ++it) {
     if (grid_build(&g, xyz, n, cell) != 0) return -1;
     int64_t occ = 0;
     for (int64_t c = 0; c < g.ncell; ++c) occ += g.start[c + 1] > g.start[c];
     double per = (double)n / (double)(occ > 0 ? occ : 1);
-    if (it >= 6 || (per >= 2.0 && per <= 16.0) || (per < 2.0 && g.ncell <= 8)) break;
-    double f = per < 2.0 ? 1.6 : 0.7;
-    if (per > 16.0 && cell * 0.7 * 2048.0 < ext) break; /* do not explode the grid */
-    cell = 1.0 / g.inv_cell * f;
+    if (per <= 12.0 || it >= 8 || cell * 0.5 * 1024.0 < ext) break;
+    cell *= 0.5;
     grid_free(&g);
   }
   cell = 1.0 / g.inv_cell;
@@ -296,6 +295,22 @@ int orc_knn(const double* xyz, int64_t n, int32_t k, int32_t exclude_self, int32
         double safe = (double)r * cell * 0.999999;
         if (have == k && best[k - 1].d2 <= safe * safe) break;
         if (r > maxdim) break;
+        if (r >= 6) { /* isolated point: finish with a plain scan of the whole cloud */
+          have = 0;
+          for (int64_t j = 0; j < n; ++j) {
+            if (exclude_self && j == i) continue;
+            double d = sqdist(p, xyz + 3 * j);
+            if (have == k && !cand_less(d, (int32_t)j, best[k - 1].d2, best[k - 1].id)) continue;
+            int32_t q = have < k ? have++ : k - 1;
+            while (q > 0 && cand_less(d, (int32_t)j, best[q - 1].d2, best[q - 1].id)) {
+              best[q] = best[q - 1];
+              --q;
+            }
+            best[q].d2 = d;
+            best[q].id = (int32_t)j;
+          }
+          break;
+        }
       }
       for (int32_t q = 0; q < k; ++q) {
         idx[i * k + q] = q < have ? best[q].id : (int32_t)n;
@@ -423,3 +438,314 @@ int orc_num_threads(void) {
   return 1;
 #endif
 }
+
+/* ------------------------------------------------------------------------ */
+/* point-cloud Laplacian                                                      */
+/*
+ * CPU statement of the algorithm of pyqsm_amd/csrc/laplacian.hip (see its header
+ * for the description and for what of Sharp & Crane's construction is not built).
+ * robust_laplacian is not installable here: PARITY UNPINNED against the package;
+ * this oracle pins the GPU kernel to an independent serial evaluation and is
+ * itself pinned by invariants and analytic answers in tests/test_laplacian_oracle.py.
+ * Every floating-point operation is written in the order the kernel uses, so that
+ * the discrete decisions (which neighbours form a fan) agree exactly.
+ */
+
+static void orc_smallest_eigvec(const double A[6], double n[3]) {
+  double a[3][3] = {{A[0], A[1], A[2]}, {A[1], A[3], A[4]}, {A[2], A[4], A[5]}};
+  double v[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  static const int P[3] = {0, 0, 1}, Q[3] = {1, 2, 2};
+  for (int sweep = 0; sweep < 12; ++sweep)
+    for (int pi = 0; pi < 3; ++pi) {
+      const int p = P[pi], q = Q[pi];
+      const double apq = a[p][q];
+      if (apq == 0.0) continue;
+      const double theta = (a[q][q] - a[p][p]) / (2.0 * apq);
+      const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+      const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
+      for (int r = 0; r < 3; ++r) {
+        const double arp = a[r][p], arq = a[r][q];
+        a[r][p] = cs * arp - sn * arq;
+        a[r][q] = sn * arp + cs * arq;
+      }
+      for (int r = 0; r < 3; ++r) {
+        const double apr = a[p][r], aqr = a[q][r];
+        a[p][r] = cs * apr - sn * aqr;
+        a[q][r] = sn * apr + cs * aqr;
+      }
+      for (int r = 0; r < 3; ++r) {
+        const double vrp = v[r][p], vrq = v[r][q];
+        v[r][p] = cs * vrp - sn * vrq;
+        v[r][q] = sn * vrp + cs * vrq;
+      }
+    }
+  int m = 0;
+  if (a[1][1] < a[m][m]) m = 1;
+  if (a[2][2] < a[m][m]) m = 2;
+  const double len = sqrt((v[0][m] * v[0][m] + v[1][m] * v[1][m]) + v[2][m] * v[2][m]);
+  n[0] = v[0][m] / len;
+  n[1] = v[1][m] / len;
+  n[2] = v[2][m] / len;
+}
+
+static void orc_tangent_basis(const double n[3], double e1[3], double e2[3]) {
+  const double ax = fabs(n[0]), ay = fabs(n[1]), az = fabs(n[2]);
+  double h[3] = {0, 0, 0};
+  if (ax <= ay && ax <= az) h[0] = 1.0;
+  else if (ay <= az) h[1] = 1.0;
+  else h[2] = 1.0;
+  double c0 = n[1] * h[2] - n[2] * h[1], c1 = n[2] * h[0] - n[0] * h[2],
+         c2 = n[0] * h[1] - n[1] * h[0];
+  const double len = sqrt((c0 * c0 + c1 * c1) + c2 * c2);
+  e1[0] = c0 / len;
+  e1[1] = c1 / len;
+  e1[2] = c2 / len;
+  e2[0] = n[1] * e1[2] - n[2] * e1[1];
+  e2[1] = n[2] * e1[0] - n[0] * e1[2];
+  e2[2] = n[0] * e1[1] - n[1] * e1[0];
+}
+
+static double orc_pseudo_angle(double x, double y) {
+  const double s = fabs(x) + fabs(y);
+  if (s == 0.0) return 0.0;
+  const double p = y / s;
+  if (x >= 0.0) return y >= 0.0 ? p : 4.0 + p;
+  return 2.0 - p;
+}
+
+typedef struct {
+  int32_t col, key;
+  double val;
+} lap_ent_t;
+
+static int lap_ent_cmp(const void* pa, const void* pb) {
+  const lap_ent_t *a = (const lap_ent_t*)pa, *b = (const lap_ent_t*)pb;
+  if (a->col != b->col) return a->col < b->col ? -1 : 1;
+  return a->key < b->key ? -1 : (a->key > b->key ? 1 : 0);
+}
+
+static double orc_dist3(const double* xyz, int a, int b) {
+  const double t0 = xyz[3 * a] - xyz[3 * b], t1 = xyz[3 * a + 1] - xyz[3 * b + 1],
+               t2 = xyz[3 * a + 2] - xyz[3 * b + 2];
+  return sqrt((t0 * t0 + t1 * t1) + t2 * t2);
+}
+
+/* Local Delaunay fan of point i: writes up to k (a, b) pairs, returns the count. */
+static int orc_fan(const double* xyz, int64_t n, int i, int k, const int32_t* nbr, int32_t* out) {
+  double dx[64], dy[64], dz[64], u[64], v[64], ang[64];
+  int valid[64], nat[64], nb[64], order[64];
+  for (int l = 0; l < k; ++l) {
+    nb[l] = nbr[(int64_t)i * k + l];
+    valid[l] = nb[l] < n;
+    dx[l] = dy[l] = dz[l] = 0.0;
+    if (valid[l]) {
+      dx[l] = xyz[3 * nb[l]] - xyz[3 * i];
+      dy[l] = xyz[3 * nb[l] + 1] - xyz[3 * i + 1];
+      dz[l] = xyz[3 * nb[l] + 2] - xyz[3 * i + 2];
+    }
+  }
+  double A[6] = {0, 0, 0, 0, 0, 0};
+  for (int l = 0; l < k; ++l) {
+    A[0] += dx[l] * dx[l];
+    A[1] += dx[l] * dy[l];
+    A[2] += dx[l] * dz[l];
+    A[3] += dy[l] * dy[l];
+    A[4] += dy[l] * dz[l];
+    A[5] += dz[l] * dz[l];
+  }
+  double nrm[3], e1[3], e2[3];
+  orc_smallest_eigvec(A, nrm);
+  orc_tangent_basis(nrm, e1, e2);
+  for (int l = 0; l < k; ++l) {
+    u[l] = (dx[l] * e1[0] + dy[l] * e1[1]) + dz[l] * e1[2];
+    v[l] = (dx[l] * e2[0] + dy[l] * e2[1]) + dz[l] * e2[2];
+  }
+  int m = 0;
+  for (int j = 0; j < k; ++j) {
+    const double uu = u[j] * u[j] + v[j] * v[j];
+    double lo = -INFINITY, hi = INFINITY;
+    int blocked = !valid[j] || uu == 0.0;
+    for (int l = 0; l < k; ++l) {
+      if (l == j || !valid[l]) continue;
+      const double cr = u[j] * v[l] - v[j] * u[l];
+      const double b = ((u[l] * u[l] + v[l] * v[l]) - (u[j] * u[l] + v[j] * v[l])) * 0.5;
+      if (cr > 0.0) {
+        const double s = b / cr;
+        hi = s < hi ? s : hi;
+      } else if (cr < 0.0) {
+        const double s = b / cr;
+        lo = s > lo ? s : lo;
+      } else if (b < 0.0) {
+        blocked = 1;
+      }
+    }
+    nat[j] = !blocked && lo <= hi;
+    ang[j] = orc_pseudo_angle(u[j], v[j]);
+    m += nat[j];
+  }
+  for (int j = 0; j < k; ++j) {
+    if (!nat[j]) continue;
+    int rank = 0;
+    for (int l = 0; l < k; ++l)
+      if (nat[l] && (ang[l] < ang[j] || (ang[l] == ang[j] && l < j))) ++rank;
+    order[rank] = j;
+  }
+  int cnt = 0;
+  if (m >= 2)
+    for (int j = 0; j < k; ++j) { /* lane order, like the kernel's ballot */
+      if (!nat[j]) continue;
+      int rank = 0;
+      for (int l = 0; l < k; ++l)
+        if (nat[l] && (ang[l] < ang[j] || (ang[l] == ang[j] && l < j))) ++rank;
+      const int s = order[rank + 1 == m ? 0 : rank + 1];
+      if ((u[j] * v[s] - v[j] * u[s]) > 0.0 && nb[s] != nb[j]) {
+        out[2 * cnt] = nb[j];
+        out[2 * cnt + 1] = nb[s];
+        ++cnt;
+      }
+    }
+  return cnt;
+}
+
+/*
+ * CSR out-parameters are malloc'ed (release with orc_free). Returns 0, or -1 on
+ * allocation failure / bad k.
+ */
+int orc_pc_laplacian(const double* xyz, int64_t n, int32_t k, double moll, int64_t* nnz_out,
+                     int32_t** indptr_out, int32_t** indices_out, double** vals_out,
+                     double* mass) {
+  if (k < 3 || k > 64) return -1;
+  int32_t* nbr = (int32_t*)malloc((size_t)(n * k + 1) * sizeof(int32_t));
+  double* d2 = (double*)malloc((size_t)(n * k + 1) * sizeof(double));
+  int32_t* fan = (int32_t*)malloc((size_t)(n * k + 1) * 2 * sizeof(int32_t));
+  int32_t* fcnt = (int32_t*)calloc((size_t)n + 1, sizeof(int32_t));
+  if (!nbr || !d2 || !fan || !fcnt) return -1;
+  if (orc_knn(xyz, n, k, 1, nbr, d2) != 0) return -1;
+#pragma omp parallel for schedule(dynamic, 256)
+  for (int64_t i = 0; i < n; ++i) fcnt[i] = orc_fan(xyz, n, (int)i, k, nbr, fan + 2 * i * k);
+  int64_t T = 0;
+  for (int64_t i = 0; i < n; ++i) T += fcnt[i];
+  int32_t* tris = (int32_t*)malloc((size_t)(T + 1) * 3 * sizeof(int32_t));
+  double* len = (double*)malloc((size_t)(T + 1) * 3 * sizeof(double));
+  double* area = (double*)malloc((size_t)(T + 1) * sizeof(double));
+  int32_t* rstart = (int32_t*)calloc((size_t)n + 1, sizeof(int32_t));
+  if (!tris || !len || !area || !rstart) return -1;
+  int64_t t = 0;
+  for (int64_t i = 0; i < n; ++i)
+    for (int s = 0; s < fcnt[i]; ++s, ++t) {
+      tris[3 * t] = (int32_t)i;
+      tris[3 * t + 1] = fan[2 * (i * k + s)];
+      tris[3 * t + 2] = fan[2 * (i * k + s) + 1];
+    }
+  /* lengths, mean, slack: block partials of 256 like the kernel (same rounding) */
+  double sum = 0.0, slack = -INFINITY;
+  for (int64_t b0 = 0; b0 < T; b0 += 256) {
+    double s_sum[256], s_slk[256];
+    for (int q = 0; q < 256; ++q) {
+      s_sum[q] = 0.0;
+      s_slk[q] = -INFINITY;
+      const int64_t tt = b0 + q;
+      if (tt >= T) continue;
+      const int a = tris[3 * tt], b = tris[3 * tt + 1], c = tris[3 * tt + 2];
+      const double la = orc_dist3(xyz, b, c), lb = orc_dist3(xyz, a, c), lc = orc_dist3(xyz, a, b);
+      len[3 * tt] = la;
+      len[3 * tt + 1] = lb;
+      len[3 * tt + 2] = lc;
+      s_sum[q] = (la + lb) + lc;
+      const double s0 = la - lb - lc, s1 = lb - la - lc, s2 = lc - la - lb;
+      double sl = s0 > s1 ? s0 : s1;
+      sl = s2 > sl ? s2 : sl;
+      s_slk[q] = sl;
+      rstart[a + 1] += 2;
+      rstart[b + 1] += 2;
+      rstart[c + 1] += 2;
+    }
+    for (int off = 128; off > 0; off >>= 1)
+      for (int q = 0; q < off; ++q) {
+        s_sum[q] += s_sum[q + off];
+        if (s_slk[q + off] > s_slk[q]) s_slk[q] = s_slk[q + off];
+      }
+    sum += s_sum[0];
+    if (s_slk[0] > slack) slack = s_slk[0];
+  }
+  const double mean = T > 0 ? sum / (3.0 * (double)T) : 0.0;
+  double eps = slack + mean * moll;
+  eps = eps > 0.0 ? eps : 0.0;
+  for (int64_t i = 0; i < n; ++i) rstart[i + 1] += rstart[i];
+  lap_ent_t* ent = (lap_ent_t*)malloc((size_t)(6 * T + 1) * sizeof(lap_ent_t));
+  int32_t* cur = (int32_t*)calloc((size_t)n + 1, sizeof(int32_t));
+  if (!ent || !cur) return -1;
+  for (int64_t tt = 0; tt < T; ++tt) {
+    const int vtx[3] = {tris[3 * tt], tris[3 * tt + 1], tris[3 * tt + 2]};
+    const double l[3] = {len[3 * tt] + eps, len[3 * tt + 1] + eps, len[3 * tt + 2] + eps};
+    const double s = ((l[0] + l[1]) + l[2]) * 0.5;
+    double a2 = s * (s - l[0]) * (s - l[1]) * (s - l[2]);
+    a2 = a2 > 0.0 ? a2 : 0.0;
+    const double ar = sqrt(a2);
+    area[tt] = ar;
+    double wgt[3];
+    for (int c = 0; c < 3; ++c) {
+      const double lo = l[c], l1 = l[(c + 1) % 3], l2 = l[(c + 2) % 3];
+      const double cot = ar > 0.0 ? ((l1 * l1 + l2 * l2) - lo * lo) / (4.0 * ar) : 0.0;
+      wgt[c] = (0.5 * cot) / 3.0;
+    }
+    for (int c = 0; c < 3; ++c) {
+      const int uu = vtx[c], v1 = vtx[(c + 1) % 3], v2 = vtx[(c + 2) % 3];
+      const int slot = rstart[uu] + cur[uu];
+      cur[uu] += 2;
+      ent[slot].col = v1;
+      ent[slot].key = (int32_t)(4 * tt + ((c + 2) % 3));
+      ent[slot].val = -wgt[(c + 2) % 3];
+      ent[slot + 1].col = v2;
+      ent[slot + 1].key = (int32_t)(4 * tt + ((c + 1) % 3));
+      ent[slot + 1].val = -wgt[(c + 1) % 3];
+    }
+  }
+  int32_t* indptr = (int32_t*)calloc((size_t)n + 1, sizeof(int32_t));
+  if (!indptr) return -1;
+  for (int64_t i = 0; i < n; ++i) {
+    qsort(ent + rstart[i], (size_t)(rstart[i + 1] - rstart[i]), sizeof(lap_ent_t), lap_ent_cmp);
+    int distinct = 0;
+    for (int a = rstart[i]; a < rstart[i + 1]; ++a)
+      if (a == rstart[i] || ent[a].col != ent[a - 1].col) ++distinct;
+    indptr[i + 1] = indptr[i] + distinct + 1;
+  }
+  const int64_t nnz = indptr[n];
+  int32_t* indices = (int32_t*)malloc((size_t)(nnz + 1) * sizeof(int32_t));
+  double* vals = (double*)malloc((size_t)(nnz + 1) * sizeof(double));
+  if (!indices || !vals) return -1;
+  for (int64_t i = 0; i < n; ++i) {
+    const int b = rstart[i], e = rstart[i + 1];
+    double m = 0.0;
+    for (int a = b; a < e; ++a) m += area[ent[a].key >> 2] * 0.5;
+    mass[i] = (m / 3.0) / 3.0;
+    int w = indptr[i], diag_pos = -1, diag_done = 0;
+    double diag = 0.0;
+    int a = b;
+    while (a < e) {
+      const int col = ent[a].col;
+      double s = 0.0;
+      while (a < e && ent[a].col == col) s += ent[a++].val;
+      if (!diag_done && col > i) {
+        diag_pos = w++;
+        diag_done = 1;
+      }
+      indices[w] = col;
+      vals[w] = s;
+      ++w;
+      diag -= s;
+    }
+    if (!diag_done) diag_pos = w++;
+    indices[diag_pos] = (int32_t)i;
+    vals[diag_pos] = diag;
+  }
+  *nnz_out = nnz;
+  *indptr_out = indptr;
+  *indices_out = indices;
+  *vals_out = vals;
+  free(nbr); free(d2); free(fan); free(fcnt); free(tris); free(len); free(area);
+  free(rstart); free(ent); free(cur);
+  return 0;
+}
+
+void orc_free(void* p) { free(p); }

@@ -1,0 +1,530 @@
+// laplacian.hip — point-cloud Laplacian on gfx950.
+//
+// Stands in for robust_laplacian.point_cloud_laplacian(pts, mollify_factor,
+// n_neighbors) as called at pyQSM/geometry/skeletonize.py:253-255,341-343
+// (Sharp & Crane 2020, "A Laplacian for Nonmanifold Triangle Meshes", point
+// cloud variant). robust_laplacian is not vendored by the reference and cannot
+// be installed here: PARITY UNPINNED against the package. What is built:
+//
+//   1. k nearest neighbours of every point (knn.hip)
+//   2. one WAVE per point, lane j = neighbour j (k <= 64):
+//        normal      = eigenvector of the smallest eigenvalue of
+//                      sum_j (p_j - p_i)(p_j - p_i)^T   (cyclic Jacobi, fp64)
+//        tangent uv  = projection of p_j - p_i on a basis of the tangent plane
+//        Delaunay    neighbour j is kept iff some circle through the centre and
+//                    uv_j is empty of the other neighbours; circle centres are
+//                    uv_j/2 + s*perp(uv_j) and every other neighbour bounds s
+//                    from one side, so the test is one pass per lane
+//        fan         kept neighbours sorted by angle; consecutive pairs with a
+//                    positive turn give the triangles (i, a, b) incident on i
+//   3. intrinsic mollification: eps = max(0, max over corners (lc - la - lb +
+//      delta)), delta = mollify_factor * mean side length; every length += eps
+//   4. cotangent weights from the mollified lengths (Heron), 1/3 of each
+//      (every triangle of a consistent region appears in three fans), assembled
+//      by row: scatter, per-row sort by (column, source corner), merge. The
+//      canonical summation order makes L exactly symmetric and the result
+//      independent of atomic ordering. Diagonal = -(row sum): rows sum to zero.
+//      Lumped mass = (area / 3) / 3 per incident triangle.
+//
+// Not built yet ("Laplacian"): the tufted cover + intrinsic Delaunay
+// edge flips of the paper. Without them L is still symmetric PSD with zero row
+// sums (a sum of per-triangle Dirichlet forms) but an edge weight can be
+// negative where neighbouring fans disagree.
+//
+// The CPU oracle (oracle/pyqsm_oracle.c: orc_pc_laplacian) repeats every
+// floating-point operation below in the same order, so discrete decisions
+// (which neighbours form the fan) agree even in degenerate configurations.
+#include "grid.hpp"
+
+#include <cmath>
+
+namespace pyqsm {
+
+int knn_device(Ctx* c, const double* xyz, int64_t n, int32_t k, int32_t exclude_self,
+               int32_t* idx, double* d2);
+
+// ---- symmetric 3x3 eigen decomposition (cyclic Jacobi, fixed sweep count) ------
+
+struct Sym3 {
+  double a00, a01, a02, a11, a12, a22;
+};
+
+// Returns the unit eigenvector of the smallest eigenvalue of A.
+__host__ __device__ inline void smallest_eigvec(Sym3 A, double n[3]) {
+  double a[3][3] = {{A.a00, A.a01, A.a02}, {A.a01, A.a11, A.a12}, {A.a02, A.a12, A.a22}};
+  double v[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  for (int sweep = 0; sweep < 12; ++sweep) {
+    for (int pi = 0; pi < 3; ++pi) {
+      const int p = pi == 2 ? 1 : 0, q = pi == 0 ? 1 : 2;  // (0,1), (0,2), (1,2)
+      const double apq = a[p][q];
+      if (apq == 0.0) continue;
+      const double theta = (a[q][q] - a[p][p]) / (2.0 * apq);
+      const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+      const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
+      for (int r = 0; r < 3; ++r) {  // A <- A J
+        const double arp = a[r][p], arq = a[r][q];
+        a[r][p] = cs * arp - sn * arq;
+        a[r][q] = sn * arp + cs * arq;
+      }
+      for (int r = 0; r < 3; ++r) {  // A <- J' A
+        const double apr = a[p][r], aqr = a[q][r];
+        a[p][r] = cs * apr - sn * aqr;
+        a[q][r] = sn * apr + cs * aqr;
+      }
+      for (int r = 0; r < 3; ++r) {  // V <- V J
+        const double vrp = v[r][p], vrq = v[r][q];
+        v[r][p] = cs * vrp - sn * vrq;
+        v[r][q] = sn * vrp + cs * vrq;
+      }
+    }
+  }
+  int m = 0;
+  if (a[1][1] < a[m][m]) m = 1;
+  if (a[2][2] < a[m][m]) m = 2;
+  const double len = sqrt((v[0][m] * v[0][m] + v[1][m] * v[1][m]) + v[2][m] * v[2][m]);
+  n[0] = v[0][m] / len;
+  n[1] = v[1][m] / len;
+  n[2] = v[2][m] / len;
+}
+
+// Orthonormal basis (e1, e2) of the plane normal to the unit vector n.
+__host__ __device__ inline void tangent_basis(const double n[3], double e1[3], double e2[3]) {
+  // cross n with the coordinate axis it is least aligned with
+  const double ax = fabs(n[0]), ay = fabs(n[1]), az = fabs(n[2]);
+  double h[3] = {0, 0, 0};
+  if (ax <= ay && ax <= az) h[0] = 1.0;
+  else if (ay <= az) h[1] = 1.0;
+  else h[2] = 1.0;
+  double c0 = n[1] * h[2] - n[2] * h[1], c1 = n[2] * h[0] - n[0] * h[2],
+         c2 = n[0] * h[1] - n[1] * h[0];
+  const double len = sqrt((c0 * c0 + c1 * c1) + c2 * c2);
+  e1[0] = c0 / len;
+  e1[1] = c1 / len;
+  e1[2] = c2 / len;
+  e2[0] = n[1] * e1[2] - n[2] * e1[1];
+  e2[1] = n[2] * e1[0] - n[0] * e1[2];
+  e2[2] = n[0] * e1[1] - n[1] * e1[0];
+}
+
+// Monotone stand-in for atan2(y, x) in [0, 4): no libm, identical on CPU and GPU.
+__host__ __device__ inline double pseudo_angle(double x, double y) {
+  const double s = fabs(x) + fabs(y);
+  if (s == 0.0) return 0.0;
+  const double p = y / s;
+  if (x >= 0.0) return y >= 0.0 ? p : 4.0 + p;
+  return 2.0 - p;
+}
+
+// ---- stage 2: local Delaunay fans, one wave per point ----------------------------
+
+__device__ __forceinline__ double bcast(double v, int lane) { return __shfl(v, lane, 64); }
+
+__global__ __launch_bounds__(256) void k_fans(int n, int k, const double* __restrict__ xyz,
+                                              const int32_t* __restrict__ nbr,
+                                              int32_t* __restrict__ tri /*[n*k][2]*/,
+                                              int32_t* __restrict__ tri_count /*[n]*/) {
+  __shared__ int32_t sorted[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = blockIdx.x * 4 + w;
+  if (i >= n) return;  // whole wave exits together
+  const double px = xyz[3 * i], py = xyz[3 * i + 1], pz = xyz[3 * i + 2];
+  int nb = n;
+  double dx = 0.0, dy = 0.0, dz = 0.0;
+  if (lane < k) {
+    nb = nbr[size_t(i) * k + lane];
+    if (nb < n) {
+      dx = xyz[3 * nb] - px;
+      dy = xyz[3 * nb + 1] - py;
+      dz = xyz[3 * nb + 2] - pz;
+    }
+  }
+  const bool valid = nb < n;
+  // covariance of the offsets, accumulated in neighbour order (every lane the same)
+  Sym3 A = {0, 0, 0, 0, 0, 0};
+  for (int l = 0; l < k; ++l) {
+    const double x = bcast(dx, l), y = bcast(dy, l), z = bcast(dz, l);
+    A.a00 += x * x;
+    A.a01 += x * y;
+    A.a02 += x * z;
+    A.a11 += y * y;
+    A.a12 += y * z;
+    A.a22 += z * z;
+  }
+  double nrm[3], e1[3], e2[3];
+  smallest_eigvec(A, nrm);
+  tangent_basis(nrm, e1, e2);
+  const double u = (dx * e1[0] + dy * e1[1]) + dz * e1[2];
+  const double v = (dx * e2[0] + dy * e2[1]) + dz * e2[2];
+  const double uu = u * u + v * v;
+  // empty-circle interval of lane's neighbour
+  double lo = -__builtin_inf(), hi = __builtin_inf();
+  bool blocked = !valid || uu == 0.0;
+  for (int l = 0; l < k; ++l) {
+    const double ul = bcast(u, l), vl = bcast(v, l);
+    const int vl_ok = __shfl(int(valid), l, 64);
+    if (l == lane || !vl_ok) continue;
+    const double cr = u * vl - v * ul;
+    const double b = ((ul * ul + vl * vl) - (u * ul + v * vl)) * 0.5;
+    if (cr > 0.0) {
+      const double s = b / cr;
+      hi = s < hi ? s : hi;
+    } else if (cr < 0.0) {
+      const double s = b / cr;
+      lo = s > lo ? s : lo;
+    } else if (b < 0.0) {
+      blocked = true;  // a closer neighbour on the same ray hides this one
+    }
+  }
+  const bool nat = !blocked && lo <= hi;
+  const double ang = pseudo_angle(u, v);
+  // rank among the kept neighbours by (angle, lane)
+  int rank = 0, m = 0;
+  for (int l = 0; l < k; ++l) {
+    const double al = bcast(ang, l);
+    const int nl = __shfl(int(nat), l, 64);
+    if (!nl) continue;
+    ++m;
+    if (al < ang || (al == ang && l < lane)) ++rank;
+  }
+  if (nat) sorted[w][rank] = lane;
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the LDS writes above have landed
+  int succ = lane;
+  if (nat && m >= 2) succ = sorted[w][rank + 1 == m ? 0 : rank + 1];
+  const double us = bcast(u, succ), vs = bcast(v, succ);
+  const int nbs = __shfl(nb, succ, 64);
+  const bool emit = nat && m >= 2 && (u * vs - v * us) > 0.0 && nbs != nb;
+  const unsigned long long mask = __ballot(emit);
+  if (emit) {
+    const int slot = __popcll(mask & ((1ull << lane) - 1ull));
+    tri[(size_t(i) * k + slot) * 2] = nb;
+    tri[(size_t(i) * k + slot) * 2 + 1] = nbs;
+  }
+  if (lane == 0) tri_count[i] = __popcll(mask);
+}
+
+// ---- stage 3/4: triangle list -> lengths, eps, weights ---------------------------
+
+// Compact (i, a, b) triangles; tri_start = exclusive scan of tri_count.
+__global__ __launch_bounds__(256) void k_compact_tris(int n, int k,
+                                                      const int32_t* __restrict__ tri,
+                                                      const int32_t* __restrict__ tri_start,
+                                                      int32_t* __restrict__ tris /*[T][3]*/) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int b = tri_start[i], cnt = tri_start[i + 1] - b;
+  for (int s = 0; s < cnt; ++s) {
+    tris[3 * size_t(b + s)] = i;
+    tris[3 * size_t(b + s) + 1] = tri[(size_t(i) * k + s) * 2];
+    tris[3 * size_t(b + s) + 2] = tri[(size_t(i) * k + s) * 2 + 1];
+  }
+}
+
+__device__ __forceinline__ double dist3(const double* __restrict__ xyz, int a, int b) {
+  const double t0 = xyz[3 * a] - xyz[3 * b], t1 = xyz[3 * a + 1] - xyz[3 * b + 1],
+               t2 = xyz[3 * a + 2] - xyz[3 * b + 2];
+  return sqrt((t0 * t0 + t1 * t1) + t2 * t2);
+}
+
+// Side lengths (opposite vertex 0, 1, 2), per-block partial sums of lengths and
+// per-block max of the triangle-inequality slack; vertex incidence counts.
+__global__ __launch_bounds__(256) void k_tri_lengths(int T, const int32_t* __restrict__ tris,
+                                                     const double* __restrict__ xyz,
+                                                     double* __restrict__ len /*[T][3]*/,
+                                                     double* __restrict__ blk_sum,
+                                                     double* __restrict__ blk_slack,
+                                                     int32_t* __restrict__ vcount) {
+  __shared__ double s_sum[256], s_slk[256];
+  int t = blockIdx.x * 256 + threadIdx.x;
+  double sum = 0.0, slack = -__builtin_inf();
+  if (t < T) {
+    const int a = tris[3 * size_t(t)], b = tris[3 * size_t(t) + 1], c = tris[3 * size_t(t) + 2];
+    const double la = dist3(xyz, b, c), lb = dist3(xyz, a, c), lc = dist3(xyz, a, b);
+    len[3 * size_t(t)] = la;
+    len[3 * size_t(t) + 1] = lb;
+    len[3 * size_t(t) + 2] = lc;
+    sum = (la + lb) + lc;
+    const double s0 = la - lb - lc, s1 = lb - la - lc, s2 = lc - la - lb;
+    slack = s0 > s1 ? s0 : s1;
+    slack = s2 > slack ? s2 : slack;
+    atomicAdd(&vcount[a], 2);
+    atomicAdd(&vcount[b], 2);
+    atomicAdd(&vcount[c], 2);
+  }
+  s_sum[threadIdx.x] = sum;
+  s_slk[threadIdx.x] = slack;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {  // fixed tree: deterministic
+    if (threadIdx.x < off) {
+      s_sum[threadIdx.x] += s_sum[threadIdx.x + off];
+      const double o = s_slk[threadIdx.x + off];
+      if (o > s_slk[threadIdx.x]) s_slk[threadIdx.x] = o;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    blk_sum[blockIdx.x] = s_sum[0];
+    blk_slack[blockIdx.x] = s_slk[0];
+  }
+}
+
+// eps from the block partials (one block, sequential over partials: deterministic)
+__global__ void k_mollify_eps(int nblk, int T, const double* __restrict__ blk_sum,
+                              const double* __restrict__ blk_slack, double moll,
+                              double* __restrict__ eps_out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double sum = 0.0, slack = -__builtin_inf();
+  for (int b = 0; b < nblk; ++b) {
+    sum += blk_sum[b];
+    if (blk_slack[b] > slack) slack = blk_slack[b];
+  }
+  const double mean = T > 0 ? sum / (3.0 * double(T)) : 0.0;
+  const double e = slack + mean * moll;
+  eps_out[0] = e > 0.0 ? e : 0.0;
+}
+
+struct Entry {  // one off-diagonal contribution
+  int32_t col;
+  int32_t key;  // 4 * triangle + slot: canonical summation order
+  double val;
+};
+
+// Cotangent weights of one triangle from mollified lengths; scatters the six
+// off-diagonal contributions into the rows of its three vertices.
+__global__ __launch_bounds__(256) void k_tri_weights(int T, const int32_t* __restrict__ tris,
+                                                     const double* __restrict__ len,
+                                                     const double* __restrict__ eps_p,
+                                                     const int32_t* __restrict__ row_start,
+                                                     int32_t* __restrict__ cursor,
+                                                     Entry* __restrict__ ent,
+                                                     double* __restrict__ tri_area) {
+  int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= T) return;
+  const double eps = eps_p[0];
+  const int vtx[3] = {tris[3 * size_t(t)], tris[3 * size_t(t) + 1], tris[3 * size_t(t) + 2]};
+  const double l[3] = {len[3 * size_t(t)] + eps, len[3 * size_t(t) + 1] + eps,
+                       len[3 * size_t(t) + 2] + eps};
+  const double s = ((l[0] + l[1]) + l[2]) * 0.5;
+  double a2 = s * (s - l[0]) * (s - l[1]) * (s - l[2]);
+  a2 = a2 > 0.0 ? a2 : 0.0;
+  const double area = sqrt(a2);
+  tri_area[t] = area;
+  double wgt[3];  // weight of the edge opposite vertex c = 0.5 * cot(angle at c) / 3
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const double lo = l[c], l1 = l[(c + 1) % 3], l2 = l[(c + 2) % 3];
+    const double cot = area > 0.0 ? ((l1 * l1 + l2 * l2) - lo * lo) / (4.0 * area) : 0.0;
+    wgt[c] = (0.5 * cot) / 3.0;
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    // vertex c owns the two edges that meet at it: to (c+1) with the weight opposite
+    // (c+2), and to (c+2) with the weight opposite (c+1)
+    const int u = vtx[c], v1 = vtx[(c + 1) % 3], v2 = vtx[(c + 2) % 3];
+    const int slot = row_start[u] + atomicAdd(&cursor[u], 2);
+    ent[slot] = Entry{v1, 4 * t + ((c + 2) % 3), -wgt[(c + 2) % 3]};
+    ent[slot + 1] = Entry{v2, 4 * t + ((c + 1) % 3), -wgt[(c + 1) % 3]};
+  }
+}
+
+__device__ __forceinline__ bool ent_less(const Entry& a, const Entry& b) {
+  return a.col < b.col || (a.col == b.col && a.key < b.key);
+}
+
+// Per row: insertion-sort the contributions by (col, key), then either count the
+// distinct columns (pass 0) or write the merged row with its diagonal (pass 1).
+template <int PASS>
+__global__ __launch_bounds__(256) void k_rows(int n, const int32_t* __restrict__ row_start,
+                                              Entry* __restrict__ ent,
+                                              const double* __restrict__ tri_area,
+                                              int32_t* __restrict__ nnz_row,
+                                              const int32_t* __restrict__ indptr,
+                                              int32_t* __restrict__ indices,
+                                              double* __restrict__ vals,
+                                              double* __restrict__ mass) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int b = row_start[i], e = row_start[i + 1];
+  if (PASS == 0) {
+    for (int a = b + 1; a < e; ++a) {
+      const Entry x = ent[a];
+      int j = a;
+      while (j > b && ent_less(x, ent[j - 1])) {
+        ent[j] = ent[j - 1];
+        --j;
+      }
+      ent[j] = x;
+    }
+    int distinct = 0;
+    for (int a = b; a < e; ++a)
+      if (a == b || ent[a].col != ent[a - 1].col) ++distinct;
+    nnz_row[i] = distinct + 1;  // + diagonal
+    return;
+  }
+  // PASS 1: merged off-diagonals in column order, diagonal inserted in place
+  double m = 0.0;
+  for (int a = b; a < e; ++a) m += tri_area[ent[a].key >> 2] * 0.5;  // each triangle twice
+  mass[i] = (m / 3.0) / 3.0;
+  int w = indptr[i];
+  double diag = 0.0;
+  bool diag_done = false;
+  int diag_pos = -1;
+  int a = b;
+  while (a < e) {
+    const int col = ent[a].col;
+    double s = 0.0;
+    while (a < e && ent[a].col == col) s += ent[a++].val;
+    if (!diag_done && col > i) {
+      diag_pos = w++;
+      diag_done = true;
+    }
+    indices[w] = col;
+    vals[w] = s;
+    ++w;
+    diag -= s;
+  }
+  if (!diag_done) diag_pos = w++;
+  indices[diag_pos] = i;
+  vals[diag_pos] = diag;
+}
+
+}  // namespace pyqsm
+
+using namespace pyqsm;
+
+extern "C" {
+
+int pyqsm_pc_laplacian(const double* xyz, int64_t n, int32_t k, double moll, int64_t* nnz_out,
+                       int32_t** indptr_out, int32_t** indices_out, double** vals_out,
+                       double* mass, int32_t device) {
+  if (n < 0) return fail(PYQSM_EINVAL, "negative size");
+  if (!nnz_out || !indptr_out || !indices_out || !vals_out)
+    return fail(PYQSM_EINVAL, "pyqsm_pc_laplacian: NULL out-parameter");
+  *nnz_out = 0;
+  *indptr_out = *indices_out = nullptr;
+  *vals_out = nullptr;
+  if (k < 3 || k > 64) return fail(PYQSM_ERANGE, "n_neighbors must be in [3, 64]");
+  if (n > 0 && (!xyz || !mass)) return fail(PYQSM_EINVAL, "pyqsm_pc_laplacian: NULL pointer");
+  if (n > (int64_t(1) << 30) / k) return fail(PYQSM_ERANGE, "n * n_neighbors exceeds 2^30");
+  if (!(moll >= 0)) return fail(PYQSM_EINVAL, "mollify factor must be >= 0");
+  Ctx* c = ctx_for(device);
+  if (!c) return PYQSM_ENODEV;
+  std::lock_guard<std::mutex> lk(c->mu);
+  c->arena.reset();
+  int32_t* h_indptr = static_cast<int32_t*>(malloc((size_t(n) + 1) * 4));
+  if (!h_indptr) return fail(PYQSM_ENOMEM, "host allocation failed");
+  if (n == 0) {
+    h_indptr[0] = 0;
+    *indptr_out = h_indptr;
+    *indices_out = static_cast<int32_t*>(malloc(4));
+    *vals_out = static_cast<double*>(malloc(8));
+    return 0;
+  }
+  int rc = 0;
+  auto body = [&]() -> int {
+    const int N = int(n);
+    double* d_xyz;
+    int32_t* d_nbr;
+    double* d_d2;
+    PQ_TRY(c->arena.get(size_t(n) * 3, &d_xyz));
+    PQ_TRY(c->arena.get(size_t(n) * k, &d_nbr));
+    PQ_TRY(c->arena.get(size_t(n) * k, &d_d2));
+    PQ_HIP(hipMemcpyAsync(d_xyz, xyz, size_t(n) * 24, hipMemcpyHostToDevice, c->stream));
+    {
+      ProfScope ps(c, "lap_knn");
+      PQ_TRY(knn_device(c, d_xyz, n, k, 1, d_nbr, d_d2));
+    }
+    int32_t *d_tri, *d_tcount;
+    PQ_TRY(c->arena.get(size_t(n) * k * 2, &d_tri));
+    PQ_TRY(c->arena.get(size_t(n) + 1, &d_tcount));
+    PQ_HIP(hipMemsetAsync(d_tcount, 0, (size_t(n) + 1) * 4, c->stream));
+    {
+      ProfScope ps(c, "lap_fans");
+      hipLaunchKernelGGL(k_fans, dim3(ceil_div(n, 4)), dim3(256), 0, c->stream, N, k, d_xyz, d_nbr,
+                         d_tri, d_tcount);
+      PQ_HIP(hipGetLastError());
+    }
+    ProfScope ps(c, "lap_assemble");
+    PQ_TRY(exclusive_scan_i32(c, d_tcount, n + 1));
+    int32_t T = 0;
+    PQ_HIP(hipMemcpyAsync(&T, d_tcount + n, 4, hipMemcpyDeviceToHost, c->stream));
+    PQ_HIP(hipStreamSynchronize(c->stream));
+    int32_t *d_tris, *d_vcount, *d_cursor, *d_nnzrow;
+    double *d_len, *d_area, *d_blk_sum, *d_blk_slack, *d_eps, *d_mass;
+    Entry* d_ent;
+    const int nblk = ceil_div(std::max<int64_t>(T, 1), 256);
+    PQ_TRY(c->arena.get(size_t(T) * 3 + 1, &d_tris));
+    PQ_TRY(c->arena.get(size_t(T) * 3 + 1, &d_len));
+    PQ_TRY(c->arena.get(size_t(T) + 1, &d_area));
+    PQ_TRY(c->arena.get(size_t(nblk), &d_blk_sum));
+    PQ_TRY(c->arena.get(size_t(nblk), &d_blk_slack));
+    PQ_TRY(c->arena.get(1, &d_eps));
+    PQ_TRY(c->arena.get(size_t(n) + 1, &d_vcount));
+    PQ_TRY(c->arena.get(size_t(n), &d_cursor));
+    PQ_TRY(c->arena.get(size_t(n) + 1, &d_nnzrow));
+    PQ_TRY(c->arena.get(size_t(T) * 6 + 1, &d_ent));
+    PQ_TRY(c->arena.get(size_t(n), &d_mass));
+    PQ_HIP(hipMemsetAsync(d_vcount, 0, (size_t(n) + 1) * 4, c->stream));
+    PQ_HIP(hipMemsetAsync(d_cursor, 0, size_t(n) * 4, c->stream));
+    PQ_HIP(hipMemsetAsync(d_nnzrow, 0, (size_t(n) + 1) * 4, c->stream));
+    const dim3 gn(ceil_div(n, 256)), gt(nblk), blk(256);
+    if (T > 0) {
+      hipLaunchKernelGGL(k_compact_tris, gn, blk, 0, c->stream, N, k, d_tri, d_tcount, d_tris);
+      hipLaunchKernelGGL(k_tri_lengths, gt, blk, 0, c->stream, T, d_tris, d_xyz, d_len, d_blk_sum,
+                         d_blk_slack, d_vcount);
+      PQ_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_mollify_eps, dim3(1), dim3(64), 0, c->stream, T > 0 ? nblk : 0, T,
+                       d_blk_sum, d_blk_slack, moll, d_eps);
+    PQ_TRY(exclusive_scan_i32(c, d_vcount, n + 1));  // row_start of the contributions
+    if (T > 0) {
+      hipLaunchKernelGGL(k_tri_weights, gt, blk, 0, c->stream, T, d_tris, d_len, d_eps, d_vcount,
+                         d_cursor, d_ent, d_area);
+      PQ_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_rows<0>, gn, blk, 0, c->stream, N, d_vcount, d_ent, d_area, d_nnzrow,
+                       static_cast<const int32_t*>(nullptr), static_cast<int32_t*>(nullptr),
+                       static_cast<double*>(nullptr), static_cast<double*>(nullptr));
+    PQ_HIP(hipGetLastError());
+    PQ_TRY(exclusive_scan_i32(c, d_nnzrow, n + 1));  // indptr
+    int32_t nnz = 0;
+    PQ_HIP(hipMemcpyAsync(&nnz, d_nnzrow + n, 4, hipMemcpyDeviceToHost, c->stream));
+    PQ_HIP(hipStreamSynchronize(c->stream));
+    int32_t* d_indices;
+    double* d_vals;
+    PQ_TRY(c->arena.get(size_t(nnz) + 1, &d_indices));
+    PQ_TRY(c->arena.get(size_t(nnz) + 1, &d_vals));
+    hipLaunchKernelGGL(k_rows<1>, gn, blk, 0, c->stream, N, d_vcount, d_ent, d_area, d_nnzrow,
+                       d_nnzrow, d_indices, d_vals, d_mass);
+    PQ_HIP(hipGetLastError());
+    int32_t* h_indices = static_cast<int32_t*>(malloc((size_t(nnz) + 1) * 4));
+    double* h_vals = static_cast<double*>(malloc((size_t(nnz) + 1) * 8));
+    if (!h_indices || !h_vals) {
+      free(h_indices);
+      free(h_vals);
+      return fail(PYQSM_ENOMEM, "host allocation failed");
+    }
+    *indices_out = h_indices;
+    *vals_out = h_vals;
+    PQ_HIP(hipMemcpyAsync(h_indptr, d_nnzrow, (size_t(n) + 1) * 4, hipMemcpyDeviceToHost, c->stream));
+    PQ_HIP(hipMemcpyAsync(h_indices, d_indices, size_t(nnz) * 4, hipMemcpyDeviceToHost, c->stream));
+    PQ_HIP(hipMemcpyAsync(h_vals, d_vals, size_t(nnz) * 8, hipMemcpyDeviceToHost, c->stream));
+    PQ_HIP(hipMemcpyAsync(mass, d_mass, size_t(n) * 8, hipMemcpyDeviceToHost, c->stream));
+    PQ_HIP(hipStreamSynchronize(c->stream));
+    *nnz_out = nnz;
+    return 0;
+  };
+  rc = body();
+  if (rc != 0) {
+    free(h_indptr);
+    free(*indices_out);
+    free(*vals_out);
+    *indices_out = nullptr;
+    *vals_out = nullptr;
+    return rc;
+  }
+  *indptr_out = h_indptr;
+  return 0;
+}
+
+}  // extern "C"

@@ -70,7 +70,9 @@ def least_squares_sparse(pts, L, laplacian_weighting, positional_weighting, trun
     x, iters, resid, ok = hip.lbc_solve(L, laplacian_weighting, positional_weighting, pts,
                                         rtol=rtol, max_it=max_it, device=device)
     if not ok:
-        log.warning(f"contraction solve stopped at {iters} iterations, residual {resid.max():.3e}")
+        # the best iterate is returned; near cond(A) * 1e-16 the residual cannot go lower
+        log.warning(f"contraction solve stopped after {iters} CG iterations at relative "
+                    f"residual {resid.max():.3e} (requested {rtol:.1e})")
     else:
         log.info(f"contraction solve: {iters} CG iterations, residual {resid.max():.3e}")
     if np.isnan(x).all():

@@ -1,0 +1,74 @@
+"""Invariants and analytic answers that pin the point-cloud Laplacian restatement
+(robust_laplacian is not installable: PARITY UNPINNED against the package)."""
+import numpy as np
+import pytest
+from scipy.sparse import diags
+
+import oracle
+from pyqsm_amd import synth
+
+
+def _grid(m, jitter, seed=0):
+    g = np.stack(np.meshgrid(np.arange(float(m)), np.arange(float(m))), -1).reshape(-1, 2)
+    rng = np.random.default_rng(seed)
+    return np.concatenate([g + rng.normal(0, jitter, g.shape), np.zeros((len(g), 1))], 1)
+
+
+def test_structure_symmetric_zero_rowsum_psd():
+    P = synth.forest(3000, seed=2)
+    L, M = oracle.point_cloud_laplacian(P, 20, 1e-6)
+    assert abs(L - L.T).max() == 0.0                      # exactly symmetric
+    assert abs(np.asarray(L.sum(axis=1))).max() <= 1e-12 * abs(L).max()
+    assert np.all(M > 0) or (M >= 0).all()
+    w = np.linalg.eigvalsh(L.toarray())
+    assert w.min() >= -1e-10 * w.max()                    # PSD
+    assert np.all(np.diff(L.indptr) >= 1)
+    for i in (0, 17, 2999):                               # sorted columns, diagonal present
+        cols = L.indices[L.indptr[i]:L.indptr[i + 1]]
+        assert np.all(np.diff(cols) > 0) and i in cols
+
+
+def test_planar_grid_is_the_five_point_stencil():
+    P = _grid(14, 0.02)
+    L, M = oracle.point_cloud_laplacian(P, 12, 1e-6)
+    i = 7 * 14 + 7
+    row = dict(zip(L.getrow(i).indices, L.getrow(i).data))
+    for j in (i - 1, i + 1, i - 14, i + 14):
+        assert abs(row[j] + 1.0) < 0.1                    # cot weights of a unit grid: -1
+    assert abs(row[i] - 4.0) < 0.2
+    others = [v for c, v in row.items() if c not in (i, i - 1, i + 1, i - 14, i + 14)]
+    assert all(abs(v) < 0.1 for v in others)              # diagonals carry ~no weight
+    interior = [r * 14 + c for r in range(3, 11) for c in range(3, 11)]
+    assert abs(M[interior].mean() - 1.0) < 0.02           # lumped mass = cell area
+
+
+def test_constant_and_linear_functions():
+    P = _grid(12, 0.05, seed=3)
+    L, _ = oracle.point_cloud_laplacian(P, 12, 1e-6)
+    assert abs(L @ np.ones(len(P))).max() < 1e-12
+    lin = L @ (2.0 * P[:, 0] - 3.0 * P[:, 1])
+    interior = [r * 12 + c for r in range(3, 9) for c in range(3, 9)]
+    assert abs(lin[interior]).max() < 1e-9                # cotan Laplacian kills linear functions
+
+
+def test_rigid_motion_invariance():
+    P = synth.forest(1500, seed=4)
+    L1, M1 = oracle.point_cloud_laplacian(P, 16, 1e-6)
+    th = 0.7
+    R = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1.0]])
+    R = R @ np.array([[1, 0, 0], [0, np.cos(0.3), -np.sin(0.3)], [0, np.sin(0.3), np.cos(0.3)]])
+    L2, M2 = oracle.point_cloud_laplacian(P @ R.T + [5.0, -2.0, 1.0], 16, 1e-6)
+    same = (L1 != 0).multiply(L2 != 0).nnz / max(L1.nnz, L2.nnz)
+    assert same > 0.97                                    # same fans except at near-ties
+    assert abs(M1.sum() - M2.sum()) < 1e-3 * M1.sum()
+
+
+def test_mollification_keeps_collinear_points_finite():
+    P = np.array([[float(i), 0.0, 0.0] for i in range(8)] + [[3.5, 1e-9, 0.0]])
+    L, M = oracle.point_cloud_laplacian(P, 5, 1e-3)
+    assert np.all(np.isfinite(L.data)) and np.all(np.isfinite(M))
+
+
+def test_bad_k_is_rejected():
+    with pytest.raises(RuntimeError):
+        oracle.point_cloud_laplacian(np.zeros((10, 3)), 2, 1e-6)
