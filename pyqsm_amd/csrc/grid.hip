@@ -105,6 +105,56 @@ __global__ __launch_bounds__(256) void k_count_occupied(const int32_t* __restric
   if ((threadIdx.x & 63) == 0 && local) atomicAdd(out, local);
 }
 
+__global__ __launch_bounds__(256) void k_probe_count(const double* __restrict__ xyz, int64_t n,
+                                                     GridParams g, int32_t* __restrict__ counts) {
+  int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+  if (i >= n) return;
+  atomicAdd(&counts[cell_index(g, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2])], 1);
+}
+
+__global__ __launch_bounds__(256) void k_count_nonzero(const int32_t* __restrict__ counts,
+                                                       int64_t ncell, int32_t* __restrict__ out) {
+  int32_t local = 0;
+  for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < ncell;
+       i += int64_t(gridDim.x) * blockDim.x)
+    local += counts[i] > 0;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
+  if ((threadIdx.x & 63) == 0 && local) atomicAdd(out, local);
+}
+
+int probe_occupancy(Ctx* c, const double* xyz, int64_t n, const double box[6], double cell,
+                    double* cell_used, double* per_cell) {
+  int dims[3];
+  for (;;) {
+    double tot = 1.0;
+    for (int a = 0; a < 3; ++a) {
+      double d = std::floor((box[3 + a] - box[a]) / cell) + 3.0;
+      dims[a] = d < 2.0e9 ? int(d) : 0x7FFFFFFF;
+      tot *= d;
+    }
+    if (tot <= double(int64_t(1) << 22)) break;
+    cell *= 2.0;
+  }
+  const int64_t ncell = int64_t(dims[0]) * dims[1] * dims[2];
+  int32_t* counts;
+  PQ_TRY(c->arena.get(size_t(ncell) + 1, &counts));
+  PQ_HIP(hipMemsetAsync(counts, 0, (size_t(ncell) + 1) * 4, c->stream));
+  GridParams gp{box[0], box[1], box[2], 1.0 / cell, dims[0], dims[1], dims[2]};
+  hipLaunchKernelGGL(k_probe_count, dim3(ceil_div(n, 256)), dim3(256), 0, c->stream, xyz, n, gp,
+                     counts);
+  const int blocks = int(std::min<int64_t>(ceil_div(ncell, 256), int64_t(c->cu_count) * 8));
+  hipLaunchKernelGGL(k_count_nonzero, dim3(blocks), dim3(256), 0, c->stream, counts, ncell,
+                     counts + ncell);
+  PQ_HIP(hipGetLastError());
+  int32_t occ = 0;
+  PQ_HIP(hipMemcpyAsync(&occ, counts + ncell, 4, hipMemcpyDeviceToHost, c->stream));
+  PQ_HIP(hipStreamSynchronize(c->stream));
+  *cell_used = cell;
+  *per_cell = double(n) / double(occ > 0 ? occ : 1);
+  return 0;
+}
+
 int cloud_bbox(Ctx* c, const double* xyz, int64_t n, double mn[3], double mx[3]) {
   if (n <= 0) return fail(PYQSM_EINVAL, "bounding box of an empty cloud");
   unsigned long long* d_box = nullptr;

@@ -35,6 +35,12 @@ int build_grid(Ctx* c, const double* xyz, int64_t n, double min_cell, int64_t ma
 // Bounding box of the cloud (one reduction kernel + a 48-byte read-back).
 int cloud_bbox(Ctx* c, const double* xyz, int64_t n, double mn[3], double mx[3]);
 
+// Mean number of points per occupied cell for a grid of edge `cell` over `box`
+// (count-only pass on a grid of at most 4 M cells; the edge is doubled to fit and
+// the edge actually used is returned). Synchronises.
+int probe_occupancy(Ctx* c, const double* xyz, int64_t n, const double box[6], double cell,
+                    double* cell_used, double* per_cell);
+
 // Number of occupied cells (reads back one int; synchronises).
 int count_occupied(Ctx* c, const DevGrid& g, int64_t* occupied);
 

@@ -132,6 +132,116 @@ __global__ __launch_bounds__(T) void k_knn(int n_query, const int32_t* __restric
   }
 }
 
+
+// Wave-per-query variant for the retry levels (k <= 64): there the cells are
+// coarse and hold thousands of points, so the 64 lanes scan a run together.
+// The sorted best-k list lives in registers, element j in lane j; an insertion
+// is a ballot (position) plus one lane shift.
+__global__ __launch_bounds__(256) void k_knn_wave(int n_query,
+                                                  const int32_t* __restrict__ query_list,
+                                                  const int32_t* __restrict__ pos_of, KnnGrid g,
+                                                  const int32_t* __restrict__ start,
+                                                  const int32_t* __restrict__ order,
+                                                  const int32_t* __restrict__ cell_of,
+                                                  const double* __restrict__ sx,
+                                                  const double* __restrict__ sy,
+                                                  const double* __restrict__ sz, int k,
+                                                  int exclude_self, int n_total, int last_level,
+                                                  int32_t* __restrict__ out_idx,
+                                                  double* __restrict__ out_d2,
+                                                  int32_t* __restrict__ fail_list,
+                                                  int32_t* __restrict__ fail_count) {
+  const int lane = threadIdx.x & 63;
+  const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (qi >= n_query) return;  // whole wave
+  const int p = query_list ? pos_of[query_list[qi]] : qi;
+  const int self = order[p];
+  const double x = sx[p], y = sy[p], z = sz[p];
+  const int c = cell_of[p];
+  const int cx = c % g.nx, cy = (c / g.nx) % g.ny, cz = c / (g.nx * g.ny);
+  double bd = __builtin_inf();
+  int bi = 0x7FFFFFFF;
+  int have = 0;
+  double tau_d = __builtin_inf();
+  int tau_i = 0x7FFFFFFF;
+  bool done = false;
+  const int rmax_grid = max(g.nx, max(g.ny, g.nz));
+  for (int r = 0; r <= kMaxRing && !done; ++r) {
+    for (int dz = -r; dz <= r; ++dz) {
+      const int zz = cz + dz;
+      if (zz < 0 || zz >= g.nz) continue;
+      for (int dy = -r; dy <= r; ++dy) {
+        const int yy = cy + dy;
+        if (yy < 0 || yy >= g.ny) continue;
+        const int row = (zz * g.ny + yy) * g.nx;
+        const bool full = (dz == -r || dz == r || dy == -r || dy == r);
+        const int nseg = full ? 1 : (r > 0 ? 2 : 1);
+        for (int s = 0; s < nseg; ++s) {
+          int x0, x1;
+          if (full) {
+            x0 = cx - r;
+            x1 = cx + r;
+          } else {
+            x0 = x1 = s == 0 ? cx - r : cx + r;
+          }
+          x0 = x0 < 0 ? 0 : x0;
+          x1 = x1 >= g.nx ? g.nx - 1 : x1;
+          if (x0 > x1) continue;
+          const int qb = start[row + x0], qe = start[row + x1 + 1];
+          for (int base = qb; base < qe; base += 64) {
+            const int q = base + lane;
+            const bool valid = q < qe && !(exclude_self && q == p);
+            double d = __builtin_inf();
+            int id = 0x7FFFFFFF;
+            if (valid) {
+              d = sqdist3(x, y, z, sx[q], sy[q], sz[q]);
+              id = order[q];
+            }
+            const bool cand = valid && (have < k || d < tau_d || (d == tau_d && id < tau_i));
+            unsigned long long mask = __ballot(cand);
+            while (mask) {
+              const int l = __ffsll(mask) - 1;
+              mask &= mask - 1;
+              const double nd = __shfl(d, l, 64);
+              const int ni = __shfl(id, l, 64);
+              if (have == k && !(nd < tau_d || (nd == tau_d && ni < tau_i))) continue;
+              const bool less = lane < have && (bd < nd || (bd == nd && bi < ni));
+              const int pos = __popcll(__ballot(less));
+              const double pd = __shfl_up(bd, 1, 64);
+              const int pi = __shfl_up(bi, 1, 64);
+              const int top = have < k ? have : k - 1;
+              if (lane > pos && lane <= top) {
+                bd = pd;
+                bi = pi;
+              }
+              if (lane == pos) {
+                bd = nd;
+                bi = ni;
+              }
+              if (have < k) ++have;
+              if (have == k) {
+                tau_d = __shfl(bd, k - 1, 64);
+                tau_i = __shfl(bi, k - 1, 64);
+              }
+            }
+          }
+        }
+      }
+    }
+    const double safe = double(r) * g.cell * 0.999999;
+    if (have == k && tau_d <= safe * safe) done = true;
+    if (r >= rmax_grid) done = true;
+  }
+  if (!done && !last_level) {
+    if (lane == 0) fail_list[atomicAdd(fail_count, 1)] = self;
+    return;
+  }
+  if (lane < k) {
+    out_idx[size_t(self) * k + lane] = lane < have ? bi : n_total;
+    out_d2[size_t(self) * k + lane] = lane < have ? bd : __builtin_inf();
+  }
+}
+
 __global__ __launch_bounds__(256) void k_invert_order(int n, const int32_t* __restrict__ order,
                                                       int32_t* __restrict__ pos_of) {
   int p = blockIdx.x * 256 + threadIdx.x;
@@ -163,26 +273,39 @@ int knn_device(Ctx* c, const double* xyz, int64_t n, int32_t k, int32_t exclude_
   if (n == 0) return 0;
   const int N = int(n);
   // ---- level-0 cell edge: aim at ~k/3 points per occupied cell -----------
+  // Two count-only probes on coarse grids give the local density and how it
+  // scales with the edge (exponent ~2 for surfaces, ~3 for volumes); the edge
+  // for the target occupancy follows by extrapolation, and one corrective
+  // rebuild is allowed if the sorted grid misses the target by more than 2.5x.
   DevGrid g;
-  const int64_t max_cells = int64_t(1) << 27;
-  double cell = 0.0;
+  const int64_t max_cells = int64_t(1) << 28;
   {
     ProfScope ps(c, "knn_bin");
     double box[6];
     PQ_TRY(cloud_bbox(c, xyz, n, box, box + 3));
     double ext = std::max(box[3] - box[0], std::max(box[4] - box[1], box[5] - box[2]));
     if (!(ext > 0)) ext = 1.0;
-    cell = ext / 1024.0;
     const double target = std::max(2.0, double(k) / 3.0);
-    for (int it = 0; it < 4; ++it) {
+    double c1, per1, c2, per2, dim = 2.0, cell;
+    PQ_TRY(probe_occupancy(c, xyz, n, box, ext / 64.0, &c1, &per1));
+    if (per1 <= 1.5 * target) {
+      cell = c1 * (per1 < 0.5 * target ? 2.0 : 1.0);
+    } else {
+      PQ_TRY(probe_occupancy(c, xyz, n, box, c1 * 0.5, &c2, &per2));
+      if (c2 < c1 && per2 > 0) dim = std::log2(std::max(per1 / per2, 1.0001)) / std::log2(c1 / c2);
+      dim = std::min(3.0, std::max(1.0, dim));
+      cell = c2 * std::pow(target / per2, 1.0 / dim);
+    }
+    cell = std::max(cell, ext / 4096.0);
+    for (int it = 0; it < 2; ++it) {
       PQ_TRY(build_grid(c, xyz, n, cell, max_cells, &g, box));
+      if (it == 1) break;
       int64_t occ = 0;
       PQ_TRY(count_occupied(c, g, &occ));
       const double per = double(n) / double(occ > 0 ? occ : 1);
-      if (per >= 0.6 * target && per <= 1.7 * target) break;
+      if (per <= 2.5 * target && per >= 0.4 * target) break;
       if (per < target && g.nx <= 3 && g.ny <= 3 && g.nz <= 3) break;  // cannot coarsen further
-      double f = std::sqrt(target / per);  // surface-like data: count ~ edge^2
-      f = std::min(4.0, std::max(0.25, f));
+      const double f = std::min(4.0, std::max(0.25, std::pow(target / per, 1.0 / dim)));
       if (f < 1.0 && g.cell > cell * 1.0000001) break;  // grid already at its size cap
       cell = g.cell * f;
     }
@@ -199,7 +322,13 @@ int knn_device(Ctx* c, const double* xyz, int64_t n, int32_t k, int32_t exclude_
     {
       ProfScope ps(c, level == 0 ? "knn_search" : "knn_retry");
       int32_t* fl = (level & 1) ? fail_b : fail_a;
-      if (k <= 48)
+      if (level > 0 && k <= 64) {
+        KnnGrid kg{g.nx, g.ny, g.nz, g.cell};
+        hipLaunchKernelGGL(k_knn_wave, dim3(ceil_div(n_query, 4)), dim3(256), 0, c->stream, n_query,
+                           list, pos_of, kg, g.start, g.order, g.cell_of, g.sx, g.sy, g.sz, k,
+                           exclude_self, N, last, idx, d2, fl, fail_count);
+        PQ_HIP(hipGetLastError());
+      } else if (k <= 48)
         PQ_TRY(launch_knn<256>(c, n_query, list, pos_of, g, k, exclude_self, N, last, idx, d2, fl,
                                fail_count));
       else if (k <= 96)

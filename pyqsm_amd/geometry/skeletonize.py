@@ -31,7 +31,7 @@ except ImportError:  # flat import (pyqsm_amd/ on sys.path)
 
 _SK = config["skeletonize"]
 SOLVER_RTOL = 1e-12      # relative residual of the normal equations at which CG stops
-SOLVER_MAX_IT = 50000
+SOLVER_MAX_IT = 5_000_000   # cap on the total number of inner CG iterations
 
 
 def point_cloud_laplacian(pts, mollify_factor=1e-5, n_neighbors=30, device: int = 0):
