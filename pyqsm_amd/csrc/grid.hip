@@ -17,8 +17,12 @@ static double ord_val(unsigned long long k) {
   return d;
 }
 
+// Stage 1: one (min, max) record per block, no atomics (94 k same-address atomics
+// cost 0.56 ms in the first version of this kernel). Stage 2: one block folds the
+// records.
 __global__ __launch_bounds__(256) void k_bbox(const double* __restrict__ xyz, int64_t n,
-                                              unsigned long long* __restrict__ out /*[6]*/) {
+                                              unsigned long long* __restrict__ part /*[grid][6]*/) {
+  __shared__ unsigned long long red[4][6];
   unsigned long long mn[3] = {~0ull, ~0ull, ~0ull}, mx[3] = {0, 0, 0};
   for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < n;
        i += int64_t(gridDim.x) * blockDim.x) {
@@ -38,12 +42,45 @@ __global__ __launch_bounds__(256) void k_bbox(const double* __restrict__ xyz, in
       mx[a] = o2 > mx[a] ? o2 : mx[a];
     }
   }
+  const int w = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) {
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      atomicMin(&out[a], mn[a]);
-      atomicMax(&out[3 + a], mx[a]);
+      red[w][a] = mn[a];
+      red[w][3 + a] = mx[a];
     }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    unsigned long long v = red[0][threadIdx.x];
+    for (int q = 1; q < 4; ++q) {
+      const unsigned long long o = red[q][threadIdx.x];
+      v = threadIdx.x < 3 ? (o < v ? o : v) : (o > v ? o : v);
+    }
+    part[size_t(blockIdx.x) * 6 + threadIdx.x] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_bbox_fold(const unsigned long long* __restrict__ part,
+                                                   int nblk, unsigned long long* __restrict__ out) {
+  __shared__ unsigned long long red[256][6];
+  unsigned long long v[6] = {~0ull, ~0ull, ~0ull, 0, 0, 0};
+  for (int b = threadIdx.x; b < nblk; b += 256)
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      const unsigned long long o = part[size_t(b) * 6 + a];
+      v[a] = a < 3 ? (o < v[a] ? o : v[a]) : (o > v[a] ? o : v[a]);
+    }
+#pragma unroll
+  for (int a = 0; a < 6; ++a) red[threadIdx.x][a] = v[a];
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    unsigned long long r = red[0][threadIdx.x];
+    for (int q = 1; q < 256; ++q) {
+      const unsigned long long o = red[q][threadIdx.x];
+      r = threadIdx.x < 3 ? (o < r ? o : r) : (o > r ? o : r);
+    }
+    out[threadIdx.x] = r;
   }
 }
 
@@ -157,12 +194,12 @@ int probe_occupancy(Ctx* c, const double* xyz, int64_t n, const double box[6], d
 
 int cloud_bbox(Ctx* c, const double* xyz, int64_t n, double mn[3], double mx[3]) {
   if (n <= 0) return fail(PYQSM_EINVAL, "bounding box of an empty cloud");
-  unsigned long long* d_box = nullptr;
+  const int blocks = int(std::min<int64_t>(ceil_div(n, 256), int64_t(c->cu_count) * 4));
+  unsigned long long *d_box = nullptr, *d_part = nullptr;
   PQ_TRY(c->arena.get(6, &d_box));
-  unsigned long long init[6] = {~0ull, ~0ull, ~0ull, 0, 0, 0};
-  PQ_HIP(hipMemcpyAsync(d_box, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
-  const int blocks = int(std::min<int64_t>(ceil_div(n, 256), int64_t(c->cu_count) * 8));
-  hipLaunchKernelGGL(k_bbox, dim3(blocks), dim3(256), 0, c->stream, xyz, n, d_box);
+  PQ_TRY(c->arena.get(size_t(blocks) * 6, &d_part));
+  hipLaunchKernelGGL(k_bbox, dim3(blocks), dim3(256), 0, c->stream, xyz, n, d_part);
+  hipLaunchKernelGGL(k_bbox_fold, dim3(1), dim3(256), 0, c->stream, d_part, blocks, d_box);
   PQ_HIP(hipGetLastError());
   unsigned long long h_box[6];
   PQ_HIP(hipMemcpyAsync(h_box, d_box, sizeof(h_box), hipMemcpyDeviceToHost, c->stream));

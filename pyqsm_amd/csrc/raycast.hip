@@ -154,12 +154,8 @@ __global__ __launch_bounds__(256) void k_cast_rays(const TriRec* __restrict__ tr
     best_p[k] = PYQSM_MISS_PRIM;
   }
 
-  Tri nxt = load_tri(tri, 0);  // T >= 1 is checked by the launcher
-  for (int j = 0; j < T; ++j) {
-    // Wave-uniform address: the record arrives by scalar loads. The next record
-    // is requested before this one is consumed so its latency is covered.
-    const Tri t = nxt;
-    nxt = load_tri(tri, j + 1 < T ? j + 1 : j);
+  // One triangle against all ray pairs of this lane.
+  auto sweep = [&](const Tri t, const int j) {
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
       f2 px, py, pz, det, tvx, tvy, tvz, U;
@@ -181,7 +177,19 @@ __global__ __launch_bounds__(256) void k_cast_rays(const TriRec* __restrict__ tr
         }
       }
     }
+  };
+  // Wave-uniform addresses: records arrive by scalar loads. Two register sets
+  // alternate so that the next record is in flight while this one is consumed
+  // and no register copies are needed. T >= 1 is checked by the launcher.
+  Tri ta = load_tri(tri, 0);
+  int j = 0;
+  for (; j + 1 < T; j += 2) {
+    const Tri tb = load_tri(tri, j + 1);
+    sweep(ta, j);
+    ta = load_tri(tri, j + 2 < T ? j + 2 : j + 1);
+    sweep(tb, j + 1);
   }
+  if (j < T) sweep(ta, j);
 
 #pragma unroll
   for (int k = 0; k < RPL; ++k) {
@@ -198,6 +206,144 @@ __global__ __launch_bounds__(256) void k_cast_rays(const TriRec* __restrict__ tr
         const int q = k >> 1, h = k & 1;
         one.ox = splat(rp[q].ox[h]); one.oy = splat(rp[q].oy[h]); one.oz = splat(rp[q].oz[h]);
         one.dx = splat(rp[q].dx[h]); one.dy = splat(rp[q].dy[h]); one.dz = splat(rp[q].dz[h]);
+        f2 px, py, pz, det, tvx, tvy, tvz, U, V, Tn;
+        mt_front(one, t, px, py, pz, det, tvx, tvy, tvz, U);
+        mt_back(one, t, tvx, tvy, tvz, V, Tn);
+        u = U[0] / det[0];
+        v = V[0] / det[0];
+      }
+      uv[2 * r] = u;
+      uv[2 * r + 1] = v;
+    }
+  }
+}
+
+// ---- parallel rays (one direction for the whole batch) ---------------------------
+// Sun-angle sweeps cast millions of rays with ONE direction d. Then p = d x e2 and
+// det = e1 . p depend on the triangle only and are computed once per triangle by
+// k_dir_records with exactly the operations of mt_front, so the per-test work of
+// the front half drops from 16 to 7 packed instructions and every result stays
+// bit-identical to the general kernel.
+
+struct alignas(16) DirRec {  // 32 bytes: what the front half needs
+  float v0x, v0y, v0z, px;
+  float py, pz, det, pad;
+};
+
+struct Front {
+  float v0x, v0y, v0z, px, py, pz, det;
+};
+
+__device__ __forceinline__ Front load_front(const DirRec* __restrict__ rec, int j) {
+  const float4* p = reinterpret_cast<const float4*>(rec + j);
+  const float4 a = p[0], b = p[1];
+  return Front{a.x, a.y, a.z, a.w, b.x, b.y, b.z};
+}
+
+__global__ void k_dir_records(const TriRec* __restrict__ tri, int64_t T,
+                              const float* __restrict__ rays, DirRec* __restrict__ out) {
+  int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+  if (i >= T) return;
+  const Tri t = load_tri(tri, int(i));
+  RayPair r;
+  r.ox = r.oy = r.oz = splat(0.f);
+  r.dx = splat(rays[3]);
+  r.dy = splat(rays[4]);
+  r.dz = splat(rays[5]);
+  f2 px, py, pz, det, tvx, tvy, tvz, U;
+  mt_front(r, t, px, py, pz, det, tvx, tvy, tvz, U);
+  out[i] = DirRec{t.v0x, t.v0y, t.v0z, px[0], py[0], pz[0], det[0], 0.f};
+}
+
+// flag = 1 unless every ray has bitwise the direction of ray 0
+__global__ void k_check_uniform(const float* __restrict__ rays, int64_t R,
+                                int* __restrict__ flag) {
+  const unsigned int* u = reinterpret_cast<const unsigned int*>(rays);
+  const unsigned int d0 = u[3], d1 = u[4], d2 = u[5];
+  bool diff = false;
+  for (int64_t r = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; r < R;
+       r += int64_t(gridDim.x) * blockDim.x)
+    diff |= u[6 * r + 3] != d0 || u[6 * r + 4] != d1 || u[6 * r + 5] != d2;
+  if (__builtin_amdgcn_ballot_w64(diff) != 0 && (threadIdx.x & 63) == 0) *flag = 1;
+}
+
+template <int NP>
+__global__ __launch_bounds__(256) void k_cast_parallel(const TriRec* __restrict__ tri,
+                                                       const DirRec* __restrict__ rec, int T,
+                                                       const float* __restrict__ rays, int64_t R,
+                                                       float* __restrict__ t_hit,
+                                                       uint32_t* __restrict__ prim_id,
+                                                       float* __restrict__ uv) {
+  constexpr int RPL = 2 * NP;
+  const int64_t block_base = int64_t(blockIdx.x) * (256 * RPL);
+  f2 ox[NP], oy[NP], oz[NP];
+  float best_t[RPL];
+  uint32_t best_p[RPL];
+#pragma unroll
+  for (int k = 0; k < RPL; ++k) {
+    int64_t r = block_base + int64_t(k) * 256 + threadIdx.x;
+    float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+    if (r < R) {
+      const float* p = rays + 6 * r;
+      o0 = p[0]; o1 = p[1]; o2 = p[2];
+    }
+    ox[k >> 1][k & 1] = o0; oy[k >> 1][k & 1] = o1; oz[k >> 1][k & 1] = o2;
+    best_t[k] = __builtin_inff();
+    best_p[k] = PYQSM_MISS_PRIM;
+  }
+  const float d0 = rays[3], d1 = rays[4], d2 = rays[5];  // the common direction
+
+  auto sweep = [&](const Front f, const int j) {
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      const f2 tvx = ox[q] - splat(f.v0x), tvy = oy[q] - splat(f.v0y), tvz = oz[q] - splat(f.v0z);
+      const f2 U = fma2(tvx, splat(f.px), fma2(tvy, splat(f.py), tvz * splat(f.pz)));
+      const f2 det = splat(f.det);
+      const f2 key = alive_key(det, U);
+      bool alive = u_alive(key[0], f.det) || u_alive(key[1], f.det);
+      if (__builtin_amdgcn_ballot_w64(alive) != 0) {  // rare: fetch the edges and finish
+        const Tri t = load_tri(tri, j);
+        RayPair r;
+        r.dx = splat(d0); r.dy = splat(d1); r.dz = splat(d2);
+        f2 V, Tn;
+        mt_back(r, t, tvx, tvy, tvz, V, Tn);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          if (is_hit(f.det, U[h], V[h], Tn[h])) {
+            float tt = Tn[h] / f.det;
+            if (tt < best_t[2 * q + h]) {
+              best_t[2 * q + h] = tt;
+              best_p[2 * q + h] = uint32_t(j);
+            }
+          }
+        }
+      }
+    }
+  };
+  Front fa = load_front(rec, 0);
+  int j = 0;
+  for (; j + 1 < T; j += 2) {
+    const Front fb = load_front(rec, j + 1);
+    sweep(fa, j);
+    fa = load_front(rec, j + 2 < T ? j + 2 : j + 1);
+    sweep(fb, j + 1);
+  }
+  if (j < T) sweep(fa, j);
+
+#pragma unroll
+  for (int k = 0; k < RPL; ++k) {
+    int64_t r = block_base + int64_t(k) * 256 + threadIdx.x;
+    if (r >= R) continue;
+    t_hit[r] = best_t[k];
+    prim_id[r] = best_p[k];
+    if (uv) {
+      float u = 0.f, v = 0.f;
+      if (best_p[k] != PYQSM_MISS_PRIM) {
+        const Tri t = load_tri(tri, int(best_p[k]));
+        RayPair one;
+        const int q = k >> 1, h = k & 1;
+        one.ox = splat(ox[q][h]); one.oy = splat(oy[q][h]); one.oz = splat(oz[q][h]);
+        one.dx = splat(d0); one.dy = splat(d1); one.dz = splat(d2);
         f2 px, py, pz, det, tvx, tvy, tvz, U, V, Tn;
         mt_front(one, t, px, py, pz, det, tvx, tvy, tvz, U);
         mt_back(one, t, tvx, tvy, tvz, V, Tn);
@@ -305,20 +451,49 @@ static int launch_cast(Ctx* c, const TriRec* tri, int64_t T, const float* rays, 
     PQ_HIP(hipGetLastError());
     return 0;
   }
-  ProfScope ps(c, "cast_rays");
+  // Parallel rays (one direction, bitwise) take the specialised kernel.
+  int* d_flag = nullptr;
+  PQ_TRY(c->arena.get(1, &d_flag));
+  PQ_HIP(hipMemsetAsync(d_flag, 0, sizeof(int), c->stream));
+  hipLaunchKernelGGL(k_check_uniform, dim3(std::min<int64_t>(ceil_div(R, 256), 2048)), dim3(256), 0,
+                     c->stream, rays, R, d_flag);
+  PQ_HIP(hipGetLastError());
+  int varied = 0;
+  PQ_HIP(hipMemcpyAsync(&varied, d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  PQ_HIP(hipStreamSynchronize(c->stream));
   // Rays per lane: 8 when there are enough rays to fill the chip that way,
   // fewer for small batches so that more waves exist.
   const int64_t waves_needed = int64_t(c->cu_count) * 8;
-  if (R >= waves_needed * 64 * 8) {
-    hipLaunchKernelGGL(k_cast_rays<4>, dim3(ceil_div(R, 256 * 8)), dim3(256), 0, c->stream, tri,
-                       int(T), rays, R, t_hit, prim, uv);
-  } else if (R >= waves_needed * 64 * 4) {
-    hipLaunchKernelGGL(k_cast_rays<2>, dim3(ceil_div(R, 256 * 4)), dim3(256), 0, c->stream, tri,
-                       int(T), rays, R, t_hit, prim, uv);
-  } else {
-    hipLaunchKernelGGL(k_cast_rays<1>, dim3(ceil_div(R, 256 * 2)), dim3(256), 0, c->stream, tri,
-                       int(T), rays, R, t_hit, prim, uv);
+  const int np = R >= waves_needed * 64 * 8 ? 4 : (R >= waves_needed * 64 * 4 ? 2 : 1);
+  const dim3 grid(ceil_div(R, 256 * 2 * np)), block(256);
+  if (!varied) {
+    DirRec* rec = nullptr;
+    PQ_TRY(c->arena.get(size_t(T), &rec));
+    hipLaunchKernelGGL(k_dir_records, dim3(ceil_div(T, 256)), dim3(256), 0, c->stream, tri, T, rays,
+                       rec);
+    ProfScope ps(c, "cast_rays");
+    if (np == 4)
+      hipLaunchKernelGGL(k_cast_parallel<4>, grid, block, 0, c->stream, tri, rec, int(T), rays, R,
+                         t_hit, prim, uv);
+    else if (np == 2)
+      hipLaunchKernelGGL(k_cast_parallel<2>, grid, block, 0, c->stream, tri, rec, int(T), rays, R,
+                         t_hit, prim, uv);
+    else
+      hipLaunchKernelGGL(k_cast_parallel<1>, grid, block, 0, c->stream, tri, rec, int(T), rays, R,
+                         t_hit, prim, uv);
+    PQ_HIP(hipGetLastError());
+    return 0;
   }
+  ProfScope ps(c, "cast_rays");
+  if (np == 4)
+    hipLaunchKernelGGL(k_cast_rays<4>, grid, block, 0, c->stream, tri, int(T), rays, R, t_hit, prim,
+                       uv);
+  else if (np == 2)
+    hipLaunchKernelGGL(k_cast_rays<2>, grid, block, 0, c->stream, tri, int(T), rays, R, t_hit, prim,
+                       uv);
+  else
+    hipLaunchKernelGGL(k_cast_rays<1>, grid, block, 0, c->stream, tri, int(T), rays, R, t_hit, prim,
+                       uv);
   PQ_HIP(hipGetLastError());
   return 0;
 }
