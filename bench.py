@@ -40,7 +40,8 @@ FP64_PEAK_TFLOPS = 78.6      # vector fp64
 # eps-neighbour kernels, and flop per ray-triangle test
 DBSCAN_BYTES_PER_POINT = 341.0
 MT_FLOP_PER_TEST = 45.0      # full Moller-Trumbore test
-MT_FLOP_FRONT = 24.0         # what every test executes here: p (9), det (5), tv (3), U (5), key (2)
+MT_FLOP_FRONT = 10.0         # executed per test by the parallel-ray kernel: tv (3), U (5), key (2)
+                             # (p and det are per-triangle there; the general kernel executes 24)
 
 
 def parse():
@@ -67,7 +68,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     dist = torch = None
-    if world > 1:
+    # PYQSM_BENCH_FORCE_DIST=1 exercises the RCCL code path with a single rank
+    if world > 1 or os.environ.get("PYQSM_BENCH_FORCE_DIST") == "1":
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -220,8 +222,9 @@ def main():
             "roofline": {"bound": "fp32-valu", "achieved": flops, "peak": FP32_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": flops / FP32_PEAK_TFLOPS,
                          "equivalent_45flop_tflops": flops_equiv,
-                         "note": "executed flops: every test runs the 24-flop front half (p, det, "
-                                 "tv, U, cull key); the 21-flop back half runs only for waves in "
+                         "note": "executed flops: the batch has one direction, so every test runs "
+                                 "the 10-flop front half (tv, U, cull key; p and det are hoisted "
+                                 "per triangle); the 21-flop back half runs only for waves in "
                                  "which some lane can still hit and is not counted. "
                                  "equivalent_45flop_tflops prices every test at SURVEY.md §8d's "
                                  "45 flop and is NOT a utilisation figure"},
