@@ -60,6 +60,7 @@ struct Timer {
   double ms = 0.0;
   int64_t launches = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+  std::vector<int> weights;  // launches represented by each pending pair
 };
 
 struct Ctx {
@@ -81,7 +82,7 @@ Ctx* ctx_for(int device);
 // when profiling is enabled; otherwise does nothing.
 class ProfScope {
  public:
-  ProfScope(Ctx* c, const char* name);
+  ProfScope(Ctx* c, const char* name, int weight = 1);
   ~ProfScope();
 
  private:

@@ -113,7 +113,7 @@ Ctx* ctx_for(int device) {
 
 // ---- timers ---------------------------------------------------------------
 
-ProfScope::ProfScope(Ctx* c, const char* name) : c_(c) {
+ProfScope::ProfScope(Ctx* c, const char* name, int weight) : c_(c) {
   if (!c->prof) return;
   t_ = &c->timers[name];
   hipEvent_t a = nullptr, b = nullptr;
@@ -124,6 +124,7 @@ ProfScope::ProfScope(Ctx* c, const char* name) : c_(c) {
   start_ = a;
   (void)hipEventRecord(a, c->stream);
   t_->pending.emplace_back(a, b);
+  t_->weights.push_back(weight);
 }
 
 ProfScope::~ProfScope() {
@@ -135,16 +136,18 @@ static void drain_timers(Ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   for (auto& kv : c->timers) {
     Timer& t = kv.second;
-    for (auto& ev : t.pending) {
+    for (size_t i = 0; i < t.pending.size(); ++i) {
+      auto& ev = t.pending[i];
       float ms = 0.f;
       if (hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) {
         t.ms += ms;
-        t.launches += 1;
+        t.launches += t.weights[i];
       }
       (void)hipEventDestroy(ev.first);
       (void)hipEventDestroy(ev.second);
     }
     t.pending.clear();
+    t.weights.clear();
   }
 }
 

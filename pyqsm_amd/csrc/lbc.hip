@@ -18,7 +18,7 @@
 
 namespace pyqsm {
 
-static constexpr int kCheckEvery = 25;
+static constexpr int kBurst = 24;  // CG iterations per graph replay / residual check
 static constexpr double kInnerRtolDefault = 1e-6;  // B-solves inside the preconditioner
 static constexpr int kInnerMaxIt = 200000;
 static constexpr int kOuterMaxIt = 200;
@@ -89,9 +89,12 @@ __device__ __forceinline__ void reduce3_atomic(double v0, double v1, double v2, 
   }
 }
 
-// Scalars of the fused Jacobi-PCG, kept on the device.
+// Scalars of the fused Jacobi-PCG, kept on the device. Two slots alternate with
+// the iteration parity p: rz[p] is the current r.z, rz[p^1] collects the next one;
+// each kernel clears the slot that the following kernels will accumulate into, so
+// an iteration is four launches with no separate bookkeeping kernel.
 struct Scal {
-  double rz[3], pq[3], rz_new[3], rr[3], bb[3];
+  double rz[2][3], pq[2][3], rr[2][3], bb[3];
 };
 
 enum Op { OP_A = 0, OP_B = 1 };  // A = wl L L wl + wh^2 ; B = c L + wh
@@ -118,9 +121,9 @@ __global__ __launch_bounds__(256) void k_init(int n, const double* __restrict__ 
       bb[k] = bi * bi;
     }
   }
-  reduce3_atomic(rz[0], rz[1], rz[2], sc->rz);
+  reduce3_atomic(rz[0], rz[1], rz[2], sc->rz[0]);
   __syncthreads();
-  reduce3_atomic(rr[0], rr[1], rr[2], sc->rr);
+  reduce3_atomic(rr[0], rr[1], rr[2], sc->rr[1]);
   __syncthreads();
   reduce3_atomic(bb[0], bb[1], bb[2], sc->bb);
 }
@@ -134,9 +137,10 @@ __global__ __launch_bounds__(256) void k_apply_tail(int n, const double* __restr
                                                     const double* __restrict__ wh,
                                                     const double* __restrict__ v,
                                                     double* __restrict__ q,
-                                                    Scal* __restrict__ sc) {
+                                                    Scal* __restrict__ sc, int par) {
   int i = blockIdx.x * 256 + threadIdx.x;
   double pq[3] = {0, 0, 0};
+  if (sc && i < 3) sc->rz[par ^ 1][i] = 0.0;  // k_update of this iteration accumulates there
   if (i < n) {
     const double a = OP == OP_A ? wl[i] : c;
     const double h = OP == OP_A ? wh[i] * wh[i] : wh[i];
@@ -148,7 +152,49 @@ __global__ __launch_bounds__(256) void k_apply_tail(int n, const double* __restr
       pq[k] = d * qi;
     }
   }
-  if (sc) reduce3_atomic(pq[0], pq[1], pq[2], sc->pq);
+  if (sc) reduce3_atomic(pq[0], pq[1], pq[2], sc->pq[par]);
+}
+
+
+// Sparse pass fused with the operator tail: t = L v for row i, then
+//   OP_A: q_i = wl_i * t + wh_i^2 * v_i    (v here is L(wl .* dir), `dirv` the CG direction)
+//   OP_B: q_i = c * t + wh_i * v_i
+// and pq += dirv_i * q_i. Saves one launch and one 3-column stream per iteration.
+template <int OP>
+__global__ __launch_bounds__(256) void k_spmv3_tail(int n, const int32_t* __restrict__ indptr,
+                                                    const int32_t* __restrict__ indices,
+                                                    const double* __restrict__ vals,
+                                                    const double* __restrict__ x /*gathered*/,
+                                                    const double* __restrict__ wl, double c,
+                                                    const double* __restrict__ wh,
+                                                    const double* __restrict__ dirv,
+                                                    double* __restrict__ q, Scal* __restrict__ sc,
+                                                    int par) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  double pq[3] = {0, 0, 0};
+  if (sc && i < 3) sc->rz[par ^ 1][i] = 0.0;
+  if (i < n) {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    const int b = indptr[i], e = indptr[i + 1];
+    for (int j = b; j < e; ++j) {
+      const int col = indices[j];
+      const double v = vals[j];
+      a0 += v * x[3 * col];
+      a1 += v * x[3 * col + 1];
+      a2 += v * x[3 * col + 2];
+    }
+    const double a = OP == OP_A ? wl[i] : c;
+    const double h = OP == OP_A ? wh[i] * wh[i] : wh[i];
+    const double t[3] = {a0, a1, a2};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const double d = dirv[3 * i + k];
+      const double qi = a * t[k] + h * d;
+      q[3 * i + k] = qi;
+      pq[k] = d * qi;
+    }
+  }
+  if (sc) reduce3_atomic(pq[0], pq[1], pq[2], sc->pq[par]);
 }
 
 // alpha = rz/pq ; x += alpha dir ; r -= alpha q ; z = Minv r ; rz_new += r.z ; rr += r.r
@@ -156,15 +202,16 @@ __global__ __launch_bounds__(256) void k_update(int n, const double* __restrict_
                                                 const double* __restrict__ q,
                                                 const double* __restrict__ minv,
                                                 double* __restrict__ x, double* __restrict__ r,
-                                                double* __restrict__ z, Scal* __restrict__ sc) {
+                                                double* __restrict__ z, Scal* __restrict__ sc,
+                                                int par) {
   int i = blockIdx.x * 256 + threadIdx.x;
   double rz[3] = {0, 0, 0}, rr[3] = {0, 0, 0};
   if (i < n) {
     const double mi = minv[i];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      const double pqk = sc->pq[k];
-      const double alpha = pqk != 0.0 ? sc->rz[k] / pqk : 0.0;
+      const double pqk = sc->pq[par][k];
+      const double alpha = pqk != 0.0 ? sc->rz[par][k] / pqk : 0.0;
       x[3 * i + k] += alpha * dir[3 * i + k];
       const double ri = r[3 * i + k] - alpha * q[3 * i + k];
       const double zi = mi * ri;
@@ -174,35 +221,26 @@ __global__ __launch_bounds__(256) void k_update(int n, const double* __restrict_
       rr[k] = ri * ri;
     }
   }
-  reduce3_atomic(rz[0], rz[1], rz[2], sc->rz_new);
+  reduce3_atomic(rz[0], rz[1], rz[2], sc->rz[par ^ 1]);
   __syncthreads();
-  reduce3_atomic(rr[0], rr[1], rr[2], sc->rr);
+  reduce3_atomic(rr[0], rr[1], rr[2], sc->rr[par]);
 }
 
 // beta = rz_new/rz ; dir = z + beta dir
 __global__ __launch_bounds__(256) void k_direction(int n, const double* __restrict__ z,
                                                    double* __restrict__ dir,
-                                                   const Scal* __restrict__ sc) {
+                                                   Scal* __restrict__ sc, int par) {
   int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < 3) {  // slots the next iteration accumulates into
+    sc->pq[par ^ 1][i] = 0.0;
+    sc->rr[par ^ 1][i] = 0.0;
+  }
   if (i >= n) return;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    const double rzk = sc->rz[k];
-    const double beta = rzk != 0.0 ? sc->rz_new[k] / rzk : 0.0;
+    const double rzk = sc->rz[par][k];
+    const double beta = rzk != 0.0 ? sc->rz[par ^ 1][k] / rzk : 0.0;
     dir[3 * i + k] = z[3 * i + k] + beta * dir[3 * i + k];
-  }
-}
-
-// rz <- rz_new (unless `first`: rz was accumulated directly by k_init); clear
-// the accumulators of the next iteration; keep rr in rr_out
-__global__ void k_roll(Scal* sc, double* rr_out, int first) {
-  int k = threadIdx.x;
-  if (k < 3) {
-    if (!first) sc->rz[k] = sc->rz_new[k];
-    sc->rz_new[k] = 0.0;
-    sc->pq[k] = 0.0;
-    rr_out[k] = sc->rr[k];
-    sc->rr[k] = 0.0;
   }
 }
 
@@ -326,7 +364,7 @@ struct System {
 };
 
 struct Work {  // scratch of one Jacobi-PCG level
-  double *t1, *t2, *r, *z, *dir, *q, *x_best, *d_rr;
+  double *t1, *t2, *r, *z, *dir, *q, *x_best;
   Scal* sc;
 };
 
@@ -338,37 +376,55 @@ static int alloc_work(Ctx* c, int64_t n, Work* w) {
   PQ_TRY(c->arena.get(size_t(n) * 3, &w->dir));
   PQ_TRY(c->arena.get(size_t(n) * 3, &w->q));
   PQ_TRY(c->arena.get(size_t(n) * 3, &w->x_best));
-  PQ_TRY(c->arena.get(3, &w->d_rr));
   PQ_TRY(c->arena.get(1, &w->sc));
   return 0;
 }
 
 // q = Op(v) (+ pq accumulation when sc != null)
 static void apply_op(Ctx* c, const System& S, const Work& w, const double* v, double* q,
-                     Scal* sc) {
+                     Scal* sc, int par = 0) {
   const dim3 grid(ceil_div(S.n, 256)), block(256);
   if (S.op == OP_A) {
     hipLaunchKernelGGL(k_spmv3, grid, block, 0, c->stream, S.n, S.L.indptr, S.L.indices, S.L.vals,
                        S.wl, v, w.t1);
-    hipLaunchKernelGGL(k_spmv3, grid, block, 0, c->stream, S.n, S.L.indptr, S.L.indices, S.L.vals,
-                       static_cast<const double*>(nullptr), w.t1, w.t2);
-    hipLaunchKernelGGL(k_apply_tail<OP_A>, grid, block, 0, c->stream, S.n, w.t2, S.wl, 0.0, S.wh, v,
-                       q, sc);
+    hipLaunchKernelGGL(k_spmv3_tail<OP_A>, grid, block, 0, c->stream, S.n, S.L.indptr, S.L.indices,
+                       S.L.vals, w.t1, S.wl, 0.0, S.wh, v, q, sc, par);
   } else {
-    hipLaunchKernelGGL(k_spmv3, grid, block, 0, c->stream, S.n, S.L.indptr, S.L.indices, S.L.vals,
-                       static_cast<const double*>(nullptr), v, w.t1);
-    hipLaunchKernelGGL(k_apply_tail<OP_B>, grid, block, 0, c->stream, S.n, w.t1,
-                       static_cast<const double*>(nullptr), S.c, S.wh, v, q, sc);
+    hipLaunchKernelGGL(k_spmv3_tail<OP_B>, grid, block, 0, c->stream, S.n, S.L.indptr, S.L.indices,
+                       S.L.vals, v, static_cast<const double*>(nullptr), S.c, S.wh, v, q, sc, par);
   }
+}
+
+// A burst of kBurst CG iterations recorded once as a hipGraph and replayed: at a
+// few thousand points an iteration is four ~5 us launches, and replaying a graph
+// costs about a third of launching them one by one.
+struct BurstGraph {
+  const void *b, *x;
+  int op;
+  hipGraphExec_t exec;
+};
+struct GraphCache {
+  std::vector<BurstGraph> items;
+  ~GraphCache() {
+    for (auto& g : items) (void)hipGraphExecDestroy(g.exec);
+  }
+};
+
+static void launch_iteration(Ctx* c, const System& S, const Work& w, double* x, int par) {
+  const dim3 grid(ceil_div(S.n, 256)), block(256);
+  apply_op(c, S, w, w.dir, w.q, w.sc, par);
+  hipLaunchKernelGGL(k_update, grid, block, 0, c->stream, S.n, w.dir, w.q, S.minv, x, w.r, w.z,
+                     w.sc, par);
+  hipLaunchKernelGGL(k_direction, grid, block, 0, c->stream, S.n, w.z, w.dir, w.sc, par);
 }
 
 // Jacobi-preconditioned CG on Op x = b for three columns. x holds the start
 // vector (zero_start: it is taken as 0 and overwritten). Scalars stay on the
-// device; the host reads the residual every kCheckEvery iterations. Returns 0
-// when |r|/|b| <= rtol for all columns, PYQSM_ENOCONV otherwise (best iterate in x).
+// device; the host reads the residual once per burst. Returns 0 when
+// |r|/|b| <= rtol for all columns, PYQSM_ENOCONV otherwise (best iterate in x).
 static int jacobi_pcg(Ctx* c, const System& S, const Work& w, const double* b, double* x,
                       bool zero_start, double rtol, int32_t max_it, const char* prof_name,
-                      int32_t* iters, double resid[3]) {
+                      GraphCache* cache, int32_t* iters, double resid[3]) {
   const int64_t n = S.n;
   const dim3 grid(ceil_div(n, 256)), block(256);
   PQ_HIP(hipMemsetAsync(w.sc, 0, sizeof(Scal), c->stream));
@@ -388,10 +444,9 @@ static int jacobi_pcg(Ctx* c, const System& S, const Work& w, const double* b, d
   bool done = true;
   for (int k = 0; k < 3; ++k) {
     bnorm[k] = std::sqrt(h.bb[k]);
-    resid[k] = bnorm[k] > 0 ? std::sqrt(h.rr[k]) / bnorm[k] : 0.0;
+    resid[k] = bnorm[k] > 0 ? std::sqrt(h.rr[1][k]) / bnorm[k] : 0.0;
     if (resid[k] > rtol) done = false;
   }
-  hipLaunchKernelGGL(k_roll, dim3(1), dim3(64), 0, c->stream, w.sc, w.d_rr, 1);
   // Past the attainable accuracy (about cond * 1e-16) the recurrences drift and
   // the residual grows again, so the best iterate is kept and the loop stops once
   // a nearly converged residual has not improved for kStallIters iterations.
@@ -400,20 +455,36 @@ static int jacobi_pcg(Ctx* c, const System& S, const Work& w, const double* b, d
   double best_res[3] = {resid[0], resid[1], resid[2]};
   int it = 0, best_it = 0;
   bool broke = false;
+  hipGraphExec_t exec = nullptr;
   while (!done && it < max_it) {
-    const int burst = std::min<int>(kCheckEvery, max_it - it);
-    for (int bi = 0; bi < burst; ++bi) {
-      ProfScope ps(c, prof_name);
-      apply_op(c, S, w, w.dir, w.q, w.sc);
-      hipLaunchKernelGGL(k_update, grid, block, 0, c->stream, S.n, w.dir, w.q, S.minv, x, w.r, w.z,
-                         w.sc);
-      hipLaunchKernelGGL(k_direction, grid, block, 0, c->stream, S.n, w.z, w.dir, w.sc);
-      hipLaunchKernelGGL(k_roll, dim3(1), dim3(64), 0, c->stream, w.sc, w.d_rr, 0);
+    // bursts have an even length so that each one starts at parity 0
+    int burst = std::min<int>(kBurst, max_it - it);
+    if (burst < kBurst) burst += burst & 1;
+    {
+      ProfScope ps(c, prof_name, burst);
+      if (burst == kBurst && cache) {
+        if (!exec) {
+          for (auto& g : cache->items)
+            if (g.b == b && g.x == x && g.op == int(S.op)) exec = g.exec;
+        }
+        if (!exec) {
+          hipGraph_t graph = nullptr;
+          PQ_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
+          for (int bi = 0; bi < burst; ++bi) launch_iteration(c, S, w, x, bi & 1);
+          PQ_HIP(hipStreamEndCapture(c->stream, &graph));
+          PQ_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+          (void)hipGraphDestroy(graph);
+          cache->items.push_back({b, x, int(S.op), exec});
+        }
+        PQ_HIP(hipGraphLaunch(exec, c->stream));
+      } else {
+        for (int bi = 0; bi < burst; ++bi) launch_iteration(c, S, w, x, bi & 1);
+        PQ_HIP(hipGetLastError());
+      }
     }
-    PQ_HIP(hipGetLastError());
     it += burst;
     double rr[3];
-    PQ_HIP(hipMemcpyAsync(rr, w.d_rr, 24, hipMemcpyDeviceToHost, c->stream));
+    PQ_HIP(hipMemcpyAsync(rr, &w.sc->rr[1][0], 24, hipMemcpyDeviceToHost, c->stream));
     PQ_HIP(hipStreamSynchronize(c->stream));
     done = true;
     double worst = 0.0;
@@ -479,7 +550,8 @@ int lbc_solve_device(Ctx* c, const DevCsr& L, int64_t n, const double* wl, doubl
   System SA{L, N, OP_A, wl, 0.0, wh, minv_a};
   if (!(wl_uniform > 0.0)) {
     hipLaunchKernelGGL(k_diag, grid, block, 0, c->stream, N, L.indptr, L.vals, wl, wh, minv_a);
-    return jacobi_pcg(c, SA, wa, b, x, false, rtol, max_it, "lbc_cg_iter", iters, resid);
+    GraphCache cache;
+    return jacobi_pcg(c, SA, wa, b, x, false, rtol, max_it, "lbc_cg_iter", &cache, iters, resid);
   }
   // ---- B^2-preconditioned flexible CG ------------------------------------------
   double *minv_b, *r, *z, *z_old, *dir, *q, *y, *x_best;
@@ -497,6 +569,7 @@ int lbc_solve_device(Ctx* c, const DevCsr& L, int64_t n, const double* wl, doubl
                      wl_uniform, wh, minv_b);
   System SB{L, N, OP_B, nullptr, wl_uniform, wh, minv_b};
   int32_t total_inner = 0;
+  GraphCache cache;
   double kInnerRtol = kInnerRtolDefault;
   if (const char* e = getenv("PYQSM_INNER_RTOL")) {  // tuning knob
     const double v = atof(e);
@@ -507,10 +580,11 @@ int lbc_solve_device(Ctx* c, const DevCsr& L, int64_t n, const double* wl, doubl
   auto precond = [&](const double* rhs, double* out) -> int {  // out = B^-1 B^-1 rhs
     int32_t it1 = 0, it2 = 0;
     double rs[3];
-    int rc = jacobi_pcg(c, SB, wb, rhs, y, true, kInnerRtol, budget(), "lbc_inner_iter", &it1, rs);
+    int rc = jacobi_pcg(c, SB, wb, rhs, y, true, kInnerRtol, budget(), "lbc_inner_iter", &cache, &it1,
+                        rs);
     if (rc != 0 && rc != PYQSM_ENOCONV) return rc;
     total_inner += it1;
-    rc = jacobi_pcg(c, SB, wb, y, out, true, kInnerRtol, budget(), "lbc_inner_iter", &it2, rs);
+    rc = jacobi_pcg(c, SB, wb, y, out, true, kInnerRtol, budget(), "lbc_inner_iter", &cache, &it2, rs);
     if (rc != 0 && rc != PYQSM_ENOCONV) return rc;
     total_inner += it2;
     return 0;
