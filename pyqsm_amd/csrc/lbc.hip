@@ -14,7 +14,7 @@
 //   vector updates   ~ 10 three-column streams = 240*n bytes
 // All scalars (alpha, beta, dot products) stay on the device; the host looks at
 // the residual only every `kCheckEvery` iterations.
-#include "common.hpp"
+#include "sparse.hpp"
 
 namespace pyqsm {
 
@@ -23,6 +23,7 @@ static constexpr double kInnerRtolDefault = 1e-6;  // B-solves inside the precon
 static constexpr int kInnerMaxIt = 200000;
 static constexpr int kOuterMaxIt = 200;
 static constexpr int kOuterStall = 6;
+static constexpr int kAmgMaxIt = 400;   // multigrid-preconditioned CG iterations per B-solve
 static constexpr int kStallIters = 1500;
 // CG residuals are not monotone, so stagnation only counts once the solve is
 // close to its attainable accuracy
@@ -330,11 +331,6 @@ __global__ __launch_bounds__(256) void k_clamp(int64_t n3, double* __restrict__ 
   pts[i] = v;
 }
 
-struct DevCsr {
-  int32_t *indptr, *indices;
-  double* vals;
-};
-
 static int upload_csr(Ctx* c, const int32_t* indptr, const int32_t* indices, const double* vals,
                       int64_t n, DevCsr* d, int64_t* nnz_out) {
   if (n > 0x7FFFFF00LL) return fail(PYQSM_ERANGE, "more than 2^31 rows");
@@ -524,6 +520,67 @@ static int dot3_host(Ctx* c, int n, const double* a, const double* b, double* d_
   return 0;
 }
 
+
+// CG on B y = rhs preconditioned by one multigrid V-cycle; scalars on the host
+// (a few dozen iterations, each dominated by the cycle). y starts at 0.
+static int amg_pcg(Ctx* c, const System& S, const Work& w, AmgHierarchy* H, const double* rhs,
+                   double* y, double rtol, int32_t max_it, double* d_tmp, int32_t* iters,
+                   double resid[3]) {
+  const int N = S.n;
+  const dim3 grid(ceil_div(N, 256)), block(256);
+  double *r = w.r, *z = w.z, *p = w.dir, *q = w.q;
+  PQ_HIP(hipMemsetAsync(y, 0, size_t(N) * 24, c->stream));
+  PQ_HIP(hipMemcpyAsync(r, rhs, size_t(N) * 24, hipMemcpyDeviceToDevice, c->stream));
+  double bb[3], rr[3], rz[3], pq[3];
+  PQ_TRY(dot3_host(c, N, rhs, rhs, d_tmp, bb));
+  PQ_TRY(amg_vcycle(c, H, r, z));
+  PQ_HIP(hipMemcpyAsync(p, z, size_t(N) * 24, hipMemcpyDeviceToDevice, c->stream));
+  PQ_TRY(dot3_host(c, N, r, z, d_tmp, rz));
+  int it = 0;
+  bool done = false;
+  for (int k = 0; k < 3; ++k) resid[k] = bb[k] > 0 ? 1.0 : 0.0;
+  if (bb[0] == 0.0 && bb[1] == 0.0 && bb[2] == 0.0) done = true;
+  while (!done && it < max_it) {
+    ProfScope ps(c, "lbc_amg_iter");
+    hipLaunchKernelGGL(k_spmv3_tail<OP_B>, grid, block, 0, c->stream, N, S.L.indptr, S.L.indices,
+                       S.L.vals, p, static_cast<const double*>(nullptr), S.c, S.wh, p, q,
+                       static_cast<Scal*>(nullptr), 0);
+    PQ_TRY(dot3_host(c, N, p, q, d_tmp, pq));
+    S3 alpha, nalpha;
+    for (int k = 0; k < 3; ++k) {
+      alpha.v[k] = pq[k] > 0.0 ? rz[k] / pq[k] : 0.0;
+      nalpha.v[k] = -alpha.v[k];
+    }
+    hipLaunchKernelGGL(k_axpy3, grid, block, 0, c->stream, N, alpha, p, y);
+    hipLaunchKernelGGL(k_axpy3, grid, block, 0, c->stream, N, nalpha, q, r);
+    PQ_TRY(dot3_host(c, N, r, r, d_tmp, rr));
+    ++it;
+    done = true;
+    for (int k = 0; k < 3; ++k) {
+      resid[k] = bb[k] > 0 ? std::sqrt(rr[k] / bb[k]) : 0.0;
+      if (!(resid[k] <= rtol)) done = false;
+      if (!std::isfinite(resid[k])) {
+        *iters = it;
+        return fail(PYQSM_ENOCONV, "multigrid CG broke down after %d iterations", it);
+      }
+    }
+    if (done) break;
+    PQ_TRY(amg_vcycle(c, H, r, z));
+    double rz_new[3];
+    PQ_TRY(dot3_host(c, N, r, z, d_tmp, rz_new));
+    S3 beta;
+    for (int k = 0; k < 3; ++k) {
+      beta.v[k] = rz[k] != 0.0 ? rz_new[k] / rz[k] : 0.0;
+      rz[k] = rz_new[k];
+    }
+    hipLaunchKernelGGL(k_xpay3, grid, block, 0, c->stream, N, beta, z, p);
+  }
+  PQ_HIP(hipGetLastError());
+  *iters = it;
+  return done ? 0 : fail(PYQSM_ENOCONV, "multigrid CG reached %d iterations, residual %.3e", it,
+                         std::max(resid[0], std::max(resid[1], resid[2])));
+}
+
 // Device-resident contraction solve.
 //
 // Uniform Laplacian weight c (what extract_skeleton always passes): the system
@@ -568,6 +625,23 @@ int lbc_solve_device(Ctx* c, const DevCsr& L, int64_t n, const double* wl, doubl
   hipLaunchKernelGGL(k_diag_b, grid, block, 0, c->stream, N, L.indptr, L.indices, L.vals,
                      wl_uniform, wh, minv_b);
   System SB{L, N, OP_B, nullptr, wl_uniform, wh, minv_b};
+  // Optional multilevel preconditioner for the B-solves (PYQSM_AMG=1). Measured on
+  // the synthetic forests it cuts the iteration count 7-10x but each cycle costs
+  // ~40 launches, and with purely geometric aggregation it still needs ~200 cycles
+  // per solve, so Jacobi-PCG stays the default (DESIGN.md "Contraction solve").
+  AmgHierarchy* amg = nullptr;
+  const char* amg_env = getenv("PYQSM_AMG");
+  if (amg_env && amg_env[0] == '1') {
+    ProfScope ps(c, "lbc_amg_build");
+    if (amg_build(c, L, N, wl_uniform, wh, pts, &amg) != 0 || amg_levels(amg) < 2) {
+      amg_destroy(amg);
+      amg = nullptr;
+    }
+  }
+  struct AmgGuard {
+    AmgHierarchy* h;
+    ~AmgGuard() { amg_destroy(h); }
+  } amg_guard{amg};
   int32_t total_inner = 0;
   GraphCache cache;
   double kInnerRtol = kInnerRtolDefault;
@@ -580,6 +654,15 @@ int lbc_solve_device(Ctx* c, const DevCsr& L, int64_t n, const double* wl, doubl
   auto precond = [&](const double* rhs, double* out) -> int {  // out = B^-1 B^-1 rhs
     int32_t it1 = 0, it2 = 0;
     double rs[3];
+    if (amg) {
+      int rc = amg_pcg(c, SB, wb, amg, rhs, y, kInnerRtol, std::min(budget(), kAmgMaxIt), d_tmp, &it1, rs);
+      if (rc != 0 && rc != PYQSM_ENOCONV) return rc;
+      total_inner += it1;
+      rc = amg_pcg(c, SB, wb, amg, y, out, kInnerRtol, std::min(budget(), kAmgMaxIt), d_tmp, &it2, rs);
+      if (rc != 0 && rc != PYQSM_ENOCONV) return rc;
+      total_inner += it2;
+      return 0;
+    }
     int rc = jacobi_pcg(c, SB, wb, rhs, y, true, kInnerRtol, budget(), "lbc_inner_iter", &cache, &it1,
                         rs);
     if (rc != 0 && rc != PYQSM_ENOCONV) return rc;
