@@ -607,6 +607,91 @@ static int orc_fan(const double* xyz, int64_t n, int i, int k, const int32_t* nb
   return cnt;
 }
 
+
+/* ---- tufted cover + intrinsic Delaunay flips (see laplacian.hip for the description) ---- */
+
+#define ORC_DELAUNAY_TOL 1e-10
+
+static int nx3(int c) { return c == 2 ? 0 : c + 1; }
+static int pv3(int c) { return c == 0 ? 2 : c - 1; }
+
+static double heron_area(double l0, double l1, double l2) {
+  const double s = ((l0 + l1) + l2) * 0.5;
+  const double a2 = s * (s - l0) * (s - l1) * (s - l2);
+  return a2 > 0.0 ? sqrt(a2) : 0.0;
+}
+static double cot_opposite(double lo, double l1, double l2) {
+  const double area = heron_area(lo, l1, l2);
+  return area > 0.0 ? ((l1 * l1 + l2 * l2) - lo * lo) / (4.0 * area) : 0.0;
+}
+static double flipped_length(double lab, double lbk, double lka, double lal, double llb) {
+  const double kx = ((lka * lka - lbk * lbk) + lab * lab) / (2.0 * lab);
+  const double ky2 = lka * lka - kx * kx;
+  const double ky = ky2 > 0.0 ? sqrt(ky2) : 0.0;
+  const double lx = ((lal * lal - llb * llb) + lab * lab) / (2.0 * lab);
+  const double ly2 = lal * lal - lx * lx;
+  const double ly = ly2 > 0.0 ? sqrt(ly2) : 0.0;
+  const double dx = kx - lx, dy = ky + ly;
+  return sqrt(dx * dx + dy * dy);
+}
+
+typedef struct {
+  int32_t mx, code;
+} edge_rec_t;
+
+static int edge_rec_cmp(const void* pa, const void* pb) {
+  const edge_rec_t *a = (const edge_rec_t*)pa, *b = (const edge_rec_t*)pb;
+  if (a->mx != b->mx) return a->mx < b->mx ? -1 : 1;
+  return a->code < b->code ? -1 : (a->code > b->code ? 1 : 0);
+}
+
+static int cover_halfedge(int code, int fwd) {
+  const int te = code >> 1, t = te / 3, e = te % 3;
+  const int front_is_fwd = (code & 1) != 0;
+  const int use_front = fwd == front_is_fwd;
+  return use_front ? 3 * (2 * t) + e : 3 * (2 * t + 1) + (2 - e);
+}
+
+/* Try to flip the cover edge h (looked at from its smaller half-edge id). Returns 1 if flipped. */
+static int try_flip(int h, int32_t* fv, double* fl, int32_t* fn) {
+  const int f = h / 3, c = h % 3;
+  const int hg = fn[h];
+  if (hg <= h) return 0;
+  const int g = hg / 3, d = hg % 3;
+  if (g == f) return 0;
+  const double lab = fl[3 * f + c], lbk = fl[3 * f + nx3(c)], lka = fl[3 * f + pv3(c)];
+  const double lal = fl[3 * g + nx3(d)], llb = fl[3 * g + pv3(d)];
+  const double sum = cot_opposite(lab, lbk, lka) + cot_opposite(lab, lal, llb);
+  if (!(sum < -ORC_DELAUNAY_TOL)) return 0;
+  const double lkl = flipped_length(lab, lbk, lka, lal, llb);
+  if (!(heron_area(lal, lkl, lka) > 0.0) || !(heron_area(lbk, lkl, llb) > 0.0)) return 0;
+  int n_bk = fn[3 * f + nx3(c)], n_ka = fn[3 * f + pv3(c)];
+  int n_al = fn[3 * g + nx3(d)], n_lb = fn[3 * g + pv3(d)];
+  const int a = fv[3 * f + c], b = fv[3 * f + nx3(c)], k = fv[3 * f + pv3(c)], l = fv[3 * g + pv3(d)];
+  const int old_bk = 3 * f + nx3(c), old_ka = 3 * f + pv3(c), old_al = 3 * g + nx3(d),
+            old_lb = 3 * g + pv3(d);
+  int* nb[4] = {&n_bk, &n_ka, &n_al, &n_lb};
+  for (int q = 0; q < 4; ++q) {
+    int code = *nb[q];
+    if (code == old_bk) code = 3 * g + 0;
+    else if (code == old_ka) code = 3 * f + 2;
+    else if (code == old_al) code = 3 * f + 0;
+    else if (code == old_lb) code = 3 * g + 2;
+    *nb[q] = code;
+  }
+  fv[3 * f] = a; fv[3 * f + 1] = l; fv[3 * f + 2] = k;
+  fl[3 * f] = lal; fl[3 * f + 1] = lkl; fl[3 * f + 2] = lka;
+  fn[3 * f] = n_al; fn[3 * f + 1] = 3 * g + 1; fn[3 * f + 2] = n_ka;
+  fv[3 * g] = b; fv[3 * g + 1] = k; fv[3 * g + 2] = l;
+  fl[3 * g] = lbk; fl[3 * g + 1] = lkl; fl[3 * g + 2] = llb;
+  fn[3 * g] = n_bk; fn[3 * g + 1] = 3 * f + 1; fn[3 * g + 2] = n_lb;
+  if (n_al / 3 != f && n_al / 3 != g) fn[n_al] = 3 * f + 0;
+  if (n_ka / 3 != f && n_ka / 3 != g) fn[n_ka] = 3 * f + 2;
+  if (n_bk / 3 != f && n_bk / 3 != g) fn[n_bk] = 3 * g + 0;
+  if (n_lb / 3 != f && n_lb / 3 != g) fn[n_lb] = 3 * g + 2;
+  return 1;
+}
+
 /*
  * CSR out-parameters are malloc'ed (release with orc_free). Returns 0, or -1 on
  * allocation failure / bad k.
@@ -656,9 +741,6 @@ int orc_pc_laplacian(const double* xyz, int64_t n, int32_t k, double moll, int64
       double sl = s0 > s1 ? s0 : s1;
       sl = s2 > sl ? s2 : sl;
       s_slk[q] = sl;
-      rstart[a + 1] += 2;
-      rstart[b + 1] += 2;
-      rstart[c + 1] += 2;
     }
     for (int off = 128; off > 0; off >>= 1)
       for (int q = 0; q < off; ++q) {
@@ -671,43 +753,107 @@ int orc_pc_laplacian(const double* xyz, int64_t n, int32_t k, double moll, int64
   const double mean = T > 0 ? sum / (3.0 * (double)T) : 0.0;
   double eps = slack + mean * moll;
   eps = eps > 0.0 ? eps : 0.0;
+  /* ---- tufted cover ------------------------------------------------------------- */
+  const int64_t F = 2 * T;
+  int32_t* fv = (int32_t*)malloc((size_t)(3 * F + 1) * sizeof(int32_t));
+  int32_t* fn = (int32_t*)malloc((size_t)(3 * F + 1) * sizeof(int32_t));
+  double* fl = (double*)malloc((size_t)(3 * F + 1) * sizeof(double));
+  int32_t* bstart = (int32_t*)calloc((size_t)n + 2, sizeof(int32_t));
+  edge_rec_t* rec = (edge_rec_t*)malloc((size_t)(3 * T + 1) * sizeof(edge_rec_t));
+  if (!fv || !fn || !fl || !bstart || !rec) return -1;
+  for (int64_t tt = 0; tt < T; ++tt) {
+    const int v0 = tris[3 * tt], v1 = tris[3 * tt + 1], v2 = tris[3 * tt + 2];
+    const double la = len[3 * tt] + eps, lb = len[3 * tt + 1] + eps, lc = len[3 * tt + 2] + eps;
+    const int64_t f = 2 * tt, g = f + 1;
+    fv[3 * f] = v0; fv[3 * f + 1] = v1; fv[3 * f + 2] = v2;
+    fl[3 * f] = lc; fl[3 * f + 1] = la; fl[3 * f + 2] = lb;
+    fv[3 * g] = v0; fv[3 * g + 1] = v2; fv[3 * g + 2] = v1;
+    fl[3 * g] = lb; fl[3 * g + 1] = la; fl[3 * g + 2] = lc;
+    bstart[(v0 < v1 ? v0 : v1) + 1]++;
+    bstart[(v1 < v2 ? v1 : v2) + 1]++;
+    bstart[(v2 < v0 ? v2 : v0) + 1]++;
+  }
+  for (int64_t i = 0; i < n; ++i) bstart[i + 1] += bstart[i];
+  {
+    int32_t* bcur = (int32_t*)calloc((size_t)n + 1, sizeof(int32_t));
+    if (!bcur) return -1;
+    for (int64_t tt = 0; tt < T; ++tt) {
+      const int v[3] = {tris[3 * tt], tris[3 * tt + 1], tris[3 * tt + 2]};
+      for (int e = 0; e < 3; ++e) {
+        const int u = v[e], w = v[nx3(e)];
+        const int mn = u < w ? u : w, mx = u < w ? w : u;
+        const int slot = bstart[mn] + bcur[mn]++;
+        rec[slot].mx = mx;
+        rec[slot].code = (int32_t)(2 * (3 * tt + e) + (u == mn ? 1 : 0));
+      }
+    }
+    free(bcur);
+  }
+  for (int64_t i = 0; i < n; ++i) {
+    const int b0 = bstart[i], e0 = bstart[i + 1];
+    qsort(rec + b0, (size_t)(e0 - b0), sizeof(edge_rec_t), edge_rec_cmp);
+    int a = b0;
+    while (a < e0) {
+      int z = a;
+      while (z < e0 && rec[z].mx == rec[a].mx) ++z;
+      const int m = z - a;
+      for (int p = 0; p < m; ++p) {
+        const int h1 = cover_halfedge(rec[a + p].code, 1);
+        const int h2 = cover_halfedge(rec[a + (p + 1 == m ? 0 : p + 1)].code, 0);
+        fn[h1] = h2;
+        fn[h2] = h1;
+      }
+      a = z;
+    }
+  }
+  /* ---- flip to intrinsic Delaunay: sweep until a whole pass flips nothing --------- */
+  for (int pass = 0; pass < 100000; ++pass) {
+    int64_t flipped = 0;
+    for (int64_t h = 0; h < 3 * F; ++h) flipped += try_flip((int)h, fv, fl, fn);
+    if (!flipped) break;
+  }
+  /* ---- weights of the cover ------------------------------------------------------- */
+  free(area);
+  area = (double*)malloc((size_t)(F + 1) * sizeof(double));
+  if (!area) return -1;
+  memset(rstart, 0, ((size_t)n + 1) * sizeof(int32_t));
+  for (int64_t f = 0; f < F; ++f)
+    for (int c = 0; c < 3; ++c) rstart[fv[3 * f + c] + 1] += 2;
   for (int64_t i = 0; i < n; ++i) rstart[i + 1] += rstart[i];
-  lap_ent_t* ent = (lap_ent_t*)malloc((size_t)(6 * T + 1) * sizeof(lap_ent_t));
+  lap_ent_t* ent = (lap_ent_t*)malloc((size_t)(6 * F + 1) * sizeof(lap_ent_t));
   int32_t* cur = (int32_t*)calloc((size_t)n + 1, sizeof(int32_t));
   if (!ent || !cur) return -1;
-  for (int64_t tt = 0; tt < T; ++tt) {
-    const int vtx[3] = {tris[3 * tt], tris[3 * tt + 1], tris[3 * tt + 2]};
-    const double l[3] = {len[3 * tt] + eps, len[3 * tt + 1] + eps, len[3 * tt + 2] + eps};
-    const double s = ((l[0] + l[1]) + l[2]) * 0.5;
-    double a2 = s * (s - l[0]) * (s - l[1]) * (s - l[2]);
-    a2 = a2 > 0.0 ? a2 : 0.0;
-    const double ar = sqrt(a2);
-    area[tt] = ar;
+  for (int64_t f = 0; f < F; ++f) {
+    const int vtx[3] = {fv[3 * f], fv[3 * f + 1], fv[3 * f + 2]};
+    const double l[3] = {fl[3 * f + 1], fl[3 * f + 2], fl[3 * f]};
+    const double ar = heron_area(l[0], l[1], l[2]);
+    area[f] = ar * 0.5;
     double wgt[3];
     for (int c = 0; c < 3; ++c) {
-      const double lo = l[c], l1 = l[(c + 1) % 3], l2 = l[(c + 2) % 3];
+      const double lo = l[c], l1 = l[nx3(c)], l2 = l[pv3(c)];
       const double cot = ar > 0.0 ? ((l1 * l1 + l2 * l2) - lo * lo) / (4.0 * ar) : 0.0;
-      wgt[c] = (0.5 * cot) / 3.0;
+      wgt[c] = ((0.5 * cot) * 0.5) / 3.0;
     }
     for (int c = 0; c < 3; ++c) {
-      const int uu = vtx[c], v1 = vtx[(c + 1) % 3], v2 = vtx[(c + 2) % 3];
+      const int uu = vtx[c], v1 = vtx[nx3(c)], v2 = vtx[pv3(c)];
       const int slot = rstart[uu] + cur[uu];
       cur[uu] += 2;
       ent[slot].col = v1;
-      ent[slot].key = (int32_t)(4 * tt + ((c + 2) % 3));
-      ent[slot].val = -wgt[(c + 2) % 3];
+      ent[slot].key = (int32_t)(4 * f + pv3(c));
+      ent[slot].val = -wgt[pv3(c)];
       ent[slot + 1].col = v2;
-      ent[slot + 1].key = (int32_t)(4 * tt + ((c + 1) % 3));
-      ent[slot + 1].val = -wgt[(c + 1) % 3];
+      ent[slot + 1].key = (int32_t)(4 * f + nx3(c));
+      ent[slot + 1].val = -wgt[nx3(c)];
     }
   }
+  free(fv); free(fn); free(fl); free(bstart); free(rec);
   int32_t* indptr = (int32_t*)calloc((size_t)n + 1, sizeof(int32_t));
   if (!indptr) return -1;
   for (int64_t i = 0; i < n; ++i) {
     qsort(ent + rstart[i], (size_t)(rstart[i + 1] - rstart[i]), sizeof(lap_ent_t), lap_ent_cmp);
     int distinct = 0;
     for (int a = rstart[i]; a < rstart[i + 1]; ++a)
-      if (a == rstart[i] || ent[a].col != ent[a - 1].col) ++distinct;
+      if (ent[a].col != i && (a == rstart[i] || ent[a].col != ent[a - 1].col)) ++distinct;
     indptr[i + 1] = indptr[i] + distinct + 1;
   }
   const int64_t nnz = indptr[n];
@@ -726,6 +872,7 @@ int orc_pc_laplacian(const double* xyz, int64_t n, int32_t k, double moll, int64
       const int col = ent[a].col;
       double s = 0.0;
       while (a < e && ent[a].col == col) s += ent[a++].val;
+      if (col == i) continue;
       if (!diag_done && col > i) {
         diag_pos = w++;
         diag_done = 1;

@@ -26,10 +26,10 @@
 //      independent of atomic ordering. Diagonal = -(row sum): rows sum to zero.
 //      Lumped mass = (area / 3) / 3 per incident triangle.
 //
-// Not built yet ("Laplacian"): the tufted cover + intrinsic Delaunay
-// edge flips of the paper. Without them L is still symmetric PSD with zero row
-// sums (a sum of per-triangle Dirichlet forms) but an edge weight can be
-// negative where neighbouring fans disagree.
+//   5. before the weights are taken, the triangle soup is turned into its tufted
+//      cover (two glued copies of every triangle: a closed edge-manifold surface)
+//      and that surface is flipped to intrinsic Delaunay using edge lengths only;
+//      all edge weights are then non-negative (see the block comment further down).
 //
 // The CPU oracle (oracle/pyqsm_oracle.c: orc_pc_laplacian) repeats every
 // floating-point operation below in the same order, so discrete decisions
@@ -227,13 +227,12 @@ __device__ __forceinline__ double dist3(const double* __restrict__ xyz, int a, i
 }
 
 // Side lengths (opposite vertex 0, 1, 2), per-block partial sums of lengths and
-// per-block max of the triangle-inequality slack; vertex incidence counts.
+// per-block max of the triangle-inequality slack.
 __global__ __launch_bounds__(256) void k_tri_lengths(int T, const int32_t* __restrict__ tris,
                                                      const double* __restrict__ xyz,
                                                      double* __restrict__ len /*[T][3]*/,
                                                      double* __restrict__ blk_sum,
-                                                     double* __restrict__ blk_slack,
-                                                     int32_t* __restrict__ vcount) {
+                                                     double* __restrict__ blk_slack) {
   __shared__ double s_sum[256], s_slk[256];
   int t = blockIdx.x * 256 + threadIdx.x;
   double sum = 0.0, slack = -__builtin_inf();
@@ -247,9 +246,6 @@ __global__ __launch_bounds__(256) void k_tri_lengths(int T, const int32_t* __res
     const double s0 = la - lb - lc, s1 = lb - la - lc, s2 = lc - la - lb;
     slack = s0 > s1 ? s0 : s1;
     slack = s2 > slack ? s2 : slack;
-    atomicAdd(&vcount[a], 2);
-    atomicAdd(&vcount[b], 2);
-    atomicAdd(&vcount[c], 2);
   }
   s_sum[threadIdx.x] = sum;
   s_slk[threadIdx.x] = slack;
@@ -289,41 +285,272 @@ struct Entry {  // one off-diagonal contribution
   double val;
 };
 
-// Cotangent weights of one triangle from mollified lengths; scatters the six
-// off-diagonal contributions into the rows of its three vertices.
-__global__ __launch_bounds__(256) void k_tri_weights(int T, const int32_t* __restrict__ tris,
-                                                     const double* __restrict__ len,
-                                                     const double* __restrict__ eps_p,
-                                                     const int32_t* __restrict__ row_start,
-                                                     int32_t* __restrict__ cursor,
-                                                     Entry* __restrict__ ent,
-                                                     double* __restrict__ tri_area) {
+// ---- tufted cover + intrinsic Delaunay flips (Sharp & Crane 2020, sections 4-5) ------
+//
+// Every triangle of the soup gets a front copy (face 2t, corners v0 v1 v2) and a
+// back copy (face 2t+1, corners v0 v2 v1). Around each undirected edge the incident
+// triangles are taken in a fixed order; the copy of triangle p that runs along the
+// edge from the smaller to the larger vertex id is glued to the copy of triangle
+// p+1 that runs the other way. The result is a closed oriented edge-manifold surface
+// with the same vertices, on which edges that violate the intrinsic Delaunay
+// condition (cot a + cot b < 0) are flipped using edge lengths only. Half of the
+// cotangent Laplacian of that surface is the Laplacian of the soup; after the flips
+// every edge weight is non-negative.
+//
+// Cover arrays, F = 2T faces: fv[f][c] vertex of corner c, fl[f][c] length of the
+// edge corner c -> corner c+1, fn[f][c] = 3*g + d, the face/edge glued to it.
+
+static constexpr double kDelaunayTol = 1e-10;
+static constexpr int kMaxFlipRounds = 2000;
+
+__device__ __host__ inline int nx3(int c) { return c == 2 ? 0 : c + 1; }
+__device__ __host__ inline int pv3(int c) { return c == 0 ? 2 : c - 1; }
+
+__global__ __launch_bounds__(256) void k_cover_init(int T, const int32_t* __restrict__ tris,
+                                                    const double* __restrict__ len,
+                                                    const double* __restrict__ eps_p,
+                                                    int32_t* __restrict__ fv,
+                                                    double* __restrict__ fl,
+                                                    int32_t* __restrict__ bcount) {
   int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= T) return;
   const double eps = eps_p[0];
-  const int vtx[3] = {tris[3 * size_t(t)], tris[3 * size_t(t) + 1], tris[3 * size_t(t) + 2]};
-  const double l[3] = {len[3 * size_t(t)] + eps, len[3 * size_t(t) + 1] + eps,
-                       len[3 * size_t(t) + 2] + eps};
-  const double s = ((l[0] + l[1]) + l[2]) * 0.5;
-  double a2 = s * (s - l[0]) * (s - l[1]) * (s - l[2]);
-  a2 = a2 > 0.0 ? a2 : 0.0;
-  const double area = sqrt(a2);
-  tri_area[t] = area;
-  double wgt[3];  // weight of the edge opposite vertex c = 0.5 * cot(angle at c) / 3
+  const int v0 = tris[3 * size_t(t)], v1 = tris[3 * size_t(t) + 1], v2 = tris[3 * size_t(t) + 2];
+  // len[] holds the side opposite vertex 0, 1, 2
+  const double la = len[3 * size_t(t)] + eps, lb = len[3 * size_t(t) + 1] + eps,
+               lc = len[3 * size_t(t) + 2] + eps;
+  const size_t f = size_t(2) * t, g = f + 1;
+  fv[3 * f] = v0; fv[3 * f + 1] = v1; fv[3 * f + 2] = v2;
+  fl[3 * f] = lc; fl[3 * f + 1] = la; fl[3 * f + 2] = lb;
+  fv[3 * g] = v0; fv[3 * g + 1] = v2; fv[3 * g + 2] = v1;
+  fl[3 * g] = lb; fl[3 * g + 1] = la; fl[3 * g + 2] = lc;
+  // one record per undirected edge occurrence, bucketed by the smaller vertex
+  atomicAdd(&bcount[v0 < v1 ? v0 : v1], 1);
+  atomicAdd(&bcount[v1 < v2 ? v1 : v2], 1);
+  atomicAdd(&bcount[v2 < v0 ? v2 : v0], 1);
+}
+
+struct EdgeRec {
+  int32_t mx;    // larger vertex id of the edge
+  int32_t code;  // 2 * (3*t + e) + (front copy runs smaller -> larger)
+};
+
+__global__ __launch_bounds__(256) void k_edge_scatter(int T, const int32_t* __restrict__ tris,
+                                                      const int32_t* __restrict__ bstart,
+                                                      int32_t* __restrict__ bcursor,
+                                                      EdgeRec* __restrict__ rec) {
+  int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= T) return;
+  const int v[3] = {tris[3 * size_t(t)], tris[3 * size_t(t) + 1], tris[3 * size_t(t) + 2]};
+#pragma unroll
+  for (int e = 0; e < 3; ++e) {
+    const int u = v[e], w = v[nx3(e)];
+    const int mn = u < w ? u : w, mx = u < w ? w : u;
+    const int slot = bstart[mn] + atomicAdd(&bcursor[mn], 1);
+    rec[slot] = EdgeRec{mx, 2 * (3 * t + e) + (u == mn ? 1 : 0)};
+  }
+}
+
+// (face, local edge) of the copy of record `code` that runs smaller->larger (fwd)
+// or larger->smaller (!fwd).
+__device__ __host__ inline int cover_halfedge(int code, bool fwd) {
+  const int te = code >> 1, t = te / 3, e = te % 3;
+  const bool front_is_fwd = (code & 1) != 0;
+  const bool use_front = fwd == front_is_fwd;
+  return use_front ? 3 * (2 * t) + e : 3 * (2 * t + 1) + (2 - e);
+}
+
+// One thread per vertex bucket: sort the records by (mx, code), then glue each
+// run of equal mx cyclically.
+__global__ __launch_bounds__(256) void k_glue(int n, const int32_t* __restrict__ bstart,
+                                              EdgeRec* __restrict__ rec,
+                                              int32_t* __restrict__ fn) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int b = bstart[i], e = bstart[i + 1];
+  for (int a = b + 1; a < e; ++a) {
+    const EdgeRec x = rec[a];
+    int j = a;
+    while (j > b && (rec[j - 1].mx > x.mx || (rec[j - 1].mx == x.mx && rec[j - 1].code > x.code))) {
+      rec[j] = rec[j - 1];
+      --j;
+    }
+    rec[j] = x;
+  }
+  int a = b;
+  while (a < e) {
+    int z = a;
+    while (z < e && rec[z].mx == rec[a].mx) ++z;
+    const int m = z - a;
+    for (int p = 0; p < m; ++p) {
+      const int h1 = cover_halfedge(rec[a + p].code, true);
+      const int h2 = cover_halfedge(rec[a + (p + 1 == m ? 0 : p + 1)].code, false);
+      fn[h1] = h2;
+      fn[h2] = h1;
+    }
+    a = z;
+  }
+}
+
+// cot of the angle opposite side lo in a triangle with sides lo, l1, l2; area by Heron
+__device__ __host__ inline double heron_area(double l0, double l1, double l2) {
+  const double s = ((l0 + l1) + l2) * 0.5;
+  const double a2 = s * (s - l0) * (s - l1) * (s - l2);
+  return a2 > 0.0 ? sqrt(a2) : 0.0;
+}
+__device__ __host__ inline double cot_opposite(double lo, double l1, double l2) {
+  const double area = heron_area(lo, l1, l2);
+  return area > 0.0 ? ((l1 * l1 + l2 * l2) - lo * lo) / (4.0 * area) : 0.0;
+}
+
+// Length of the other diagonal of the quad made of triangles (a,b,k) and (b,a,l)
+// laid out in the plane: a = (0,0), b = (lab,0), k above, l below.
+__device__ __host__ inline double flipped_length(double lab, double lbk, double lka, double lal,
+                                                 double llb) {
+  const double kx = ((lka * lka - lbk * lbk) + lab * lab) / (2.0 * lab);
+  const double ky2 = lka * lka - kx * kx;
+  const double ky = ky2 > 0.0 ? sqrt(ky2) : 0.0;
+  const double lx = ((lal * lal - llb * llb) + lab * lab) / (2.0 * lab);
+  const double ly2 = lal * lal - lx * lx;
+  const double ly = ly2 > 0.0 ? sqrt(ly2) : 0.0;
+  const double dx = kx - lx, dy = ky + ly;
+  return sqrt(dx * dx + dy * dy);
+}
+
+struct FlipInfo {
+  int f, c, g, d;
+  double lab, lbk, lka, lal, llb, lkl;
+};
+
+// Is the cover edge (f, c) a legal flip candidate? Each edge is looked at from the
+// side with the smaller half-edge id only.
+__device__ __host__ inline bool flip_candidate(int h, const double* fl, const int32_t* fn,
+                                               FlipInfo* o) {
+  const int f = h / 3, c = h % 3;
+  const int hg = fn[h];
+  if (hg <= h) return false;  // the other side handles it (or a self-glued edge)
+  const int g = hg / 3, d = hg % 3;
+  if (g == f) return false;
+  const double lab = fl[3 * size_t(f) + c], lbk = fl[3 * size_t(f) + nx3(c)],
+               lka = fl[3 * size_t(f) + pv3(c)];
+  const double lal = fl[3 * size_t(g) + nx3(d)], llb = fl[3 * size_t(g) + pv3(d)];
+  const double sum = cot_opposite(lab, lbk, lka) + cot_opposite(lab, lal, llb);
+  if (!(sum < -kDelaunayTol)) return false;
+  const double lkl = flipped_length(lab, lbk, lka, lal, llb);
+  // both new triangles must be proper
+  if (!(heron_area(lal, lkl, lka) > 0.0) || !(heron_area(lbk, lkl, llb) > 0.0)) return false;
+  *o = FlipInfo{f, c, g, d, lab, lbk, lka, lal, llb, lkl};
+  return true;
+}
+
+// Round part 1: every candidate claims its two faces and their four outer
+// neighbours with its priority (half-edge id + 1); the largest priority wins a face.
+__global__ __launch_bounds__(256) void k_flip_claim(int H, const double* __restrict__ fl,
+                                                    const int32_t* __restrict__ fn,
+                                                    int32_t* __restrict__ claim,
+                                                    int32_t* __restrict__ n_cand) {
+  int h = blockIdx.x * 256 + threadIdx.x;
+  if (h >= H) return;
+  FlipInfo q;
+  if (!flip_candidate(h, fl, fn, &q)) return;
+  atomicAdd(n_cand, 1);
+  const int pr = h + 1;
+  atomicMax(&claim[q.f], pr);
+  atomicMax(&claim[q.g], pr);
+  atomicMax(&claim[fn[3 * size_t(q.f) + nx3(q.c)] / 3], pr);
+  atomicMax(&claim[fn[3 * size_t(q.f) + pv3(q.c)] / 3], pr);
+  atomicMax(&claim[fn[3 * size_t(q.g) + nx3(q.d)] / 3], pr);
+  atomicMax(&claim[fn[3 * size_t(q.g) + pv3(q.d)] / 3], pr);
+}
+
+// Round part 2: a candidate that owns all six faces flips its edge.
+//   before: f = (a, b, k) with edge c = a->b,   g = (b, a, l) with edge d = b->a
+//   after:  f = (a, l, k),  g = (b, k, l)       (new edge l->k in f, k->l in g)
+__global__ __launch_bounds__(256) void k_flip_apply(int H, int32_t* __restrict__ fv,
+                                                    double* __restrict__ fl,
+                                                    int32_t* __restrict__ fn,
+                                                    const int32_t* __restrict__ claim,
+                                                    int32_t* __restrict__ n_done) {
+  int h = blockIdx.x * 256 + threadIdx.x;
+  if (h >= H) return;
+  FlipInfo q;
+  if (!flip_candidate(h, fl, fn, &q)) return;
+  const int pr = h + 1;
+  const int f = q.f, c = q.c, g = q.g, d = q.d;
+  int n_bk = fn[3 * size_t(f) + nx3(c)], n_ka = fn[3 * size_t(f) + pv3(c)];
+  int n_al = fn[3 * size_t(g) + nx3(d)], n_lb = fn[3 * size_t(g) + pv3(d)];
+  if (claim[f] != pr || claim[g] != pr || claim[n_bk / 3] != pr || claim[n_ka / 3] != pr ||
+      claim[n_al / 3] != pr || claim[n_lb / 3] != pr)
+    return;
+  const int a = fv[3 * size_t(f) + c], b = fv[3 * size_t(f) + nx3(c)],
+            k = fv[3 * size_t(f) + pv3(c)], l = fv[3 * size_t(g) + pv3(d)];
+  // outer edges that are glued to f or g themselves move with the flip
+  const int old_bk = 3 * f + nx3(c), old_ka = 3 * f + pv3(c), old_al = 3 * g + nx3(d),
+            old_lb = 3 * g + pv3(d);
+  auto remap = [&](int code) {
+    if (code == old_bk) return 3 * g + 0;
+    if (code == old_ka) return 3 * f + 2;
+    if (code == old_al) return 3 * f + 0;
+    if (code == old_lb) return 3 * g + 2;
+    return code;
+  };
+  n_bk = remap(n_bk);
+  n_ka = remap(n_ka);
+  n_al = remap(n_al);
+  n_lb = remap(n_lb);
+  fv[3 * size_t(f)] = a; fv[3 * size_t(f) + 1] = l; fv[3 * size_t(f) + 2] = k;
+  fl[3 * size_t(f)] = q.lal; fl[3 * size_t(f) + 1] = q.lkl; fl[3 * size_t(f) + 2] = q.lka;
+  fn[3 * size_t(f)] = n_al; fn[3 * size_t(f) + 1] = 3 * g + 1; fn[3 * size_t(f) + 2] = n_ka;
+  fv[3 * size_t(g)] = b; fv[3 * size_t(g) + 1] = k; fv[3 * size_t(g) + 2] = l;
+  fl[3 * size_t(g)] = q.lbk; fl[3 * size_t(g) + 1] = q.lkl; fl[3 * size_t(g) + 2] = q.llb;
+  fn[3 * size_t(g)] = n_bk; fn[3 * size_t(g) + 1] = 3 * f + 1; fn[3 * size_t(g) + 2] = n_lb;
+  // back links of the outer neighbours (for neighbours inside {f, g} the forward
+  // links written above already point the right way)
+  if (n_al / 3 != f && n_al / 3 != g) fn[n_al] = 3 * f + 0;
+  if (n_ka / 3 != f && n_ka / 3 != g) fn[n_ka] = 3 * f + 2;
+  if (n_bk / 3 != f && n_bk / 3 != g) fn[n_bk] = 3 * g + 0;
+  if (n_lb / 3 != f && n_lb / 3 != g) fn[n_lb] = 3 * g + 2;
+  atomicAdd(n_done, 1);
+}
+
+__global__ __launch_bounds__(256) void k_cover_vcount(int F, const int32_t* __restrict__ fv,
+                                                      int32_t* __restrict__ vcount) {
+  int f = blockIdx.x * 256 + threadIdx.x;
+  if (f >= F) return;
+  atomicAdd(&vcount[fv[3 * size_t(f)]], 2);
+  atomicAdd(&vcount[fv[3 * size_t(f) + 1]], 2);
+  atomicAdd(&vcount[fv[3 * size_t(f) + 2]], 2);
+}
+
+// Cotangent weights of one cover face; scatters six off-diagonal contributions into
+// the rows of its three vertices. The cover counts every area twice (x 1/2) and a
+// consistent region appears in three fans (x 1/3).
+__global__ __launch_bounds__(256) void k_cover_weights(int F, const int32_t* __restrict__ fv,
+                                                       const double* __restrict__ fl,
+                                                       const int32_t* __restrict__ row_start,
+                                                       int32_t* __restrict__ cursor,
+                                                       Entry* __restrict__ ent,
+                                                       double* __restrict__ face_area) {
+  int f = blockIdx.x * 256 + threadIdx.x;
+  if (f >= F) return;
+  const int vtx[3] = {fv[3 * size_t(f)], fv[3 * size_t(f) + 1], fv[3 * size_t(f) + 2]};
+  // side opposite corner c is the edge (c+1) -> (c+2), i.e. fl[c+1]
+  const double l[3] = {fl[3 * size_t(f) + 1], fl[3 * size_t(f) + 2], fl[3 * size_t(f)]};
+  const double area = heron_area(l[0], l[1], l[2]);
+  face_area[f] = area * 0.5;
+  double wgt[3];  // weight of the edge opposite corner c
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    const double lo = l[c], l1 = l[(c + 1) % 3], l2 = l[(c + 2) % 3];
+    const double lo = l[c], l1 = l[nx3(c)], l2 = l[pv3(c)];
     const double cot = area > 0.0 ? ((l1 * l1 + l2 * l2) - lo * lo) / (4.0 * area) : 0.0;
-    wgt[c] = (0.5 * cot) / 3.0;
+    wgt[c] = ((0.5 * cot) * 0.5) / 3.0;
   }
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    // vertex c owns the two edges that meet at it: to (c+1) with the weight opposite
-    // (c+2), and to (c+2) with the weight opposite (c+1)
-    const int u = vtx[c], v1 = vtx[(c + 1) % 3], v2 = vtx[(c + 2) % 3];
+    const int u = vtx[c], v1 = vtx[nx3(c)], v2 = vtx[pv3(c)];
     const int slot = row_start[u] + atomicAdd(&cursor[u], 2);
-    ent[slot] = Entry{v1, 4 * t + ((c + 2) % 3), -wgt[(c + 2) % 3]};
-    ent[slot + 1] = Entry{v2, 4 * t + ((c + 1) % 3), -wgt[(c + 1) % 3]};
+    ent[slot] = Entry{v1, 4 * f + pv3(c), -wgt[pv3(c)]};
+    ent[slot + 1] = Entry{v2, 4 * f + nx3(c), -wgt[nx3(c)]};
   }
 }
 
@@ -357,13 +584,13 @@ __global__ __launch_bounds__(256) void k_rows(int n, const int32_t* __restrict__
     }
     int distinct = 0;
     for (int a = b; a < e; ++a)
-      if (a == b || ent[a].col != ent[a - 1].col) ++distinct;
-    nnz_row[i] = distinct + 1;  // + diagonal
+      if (ent[a].col != i && (a == b || ent[a].col != ent[a - 1].col)) ++distinct;
+    nnz_row[i] = distinct + 1;  // + diagonal (loop edges i-i carry no weight)
     return;
   }
   // PASS 1: merged off-diagonals in column order, diagonal inserted in place
   double m = 0.0;
-  for (int a = b; a < e; ++a) m += tri_area[ent[a].key >> 2] * 0.5;  // each triangle twice
+  for (int a = b; a < e; ++a) m += tri_area[ent[a].key >> 2] * 0.5;  // each face twice
   mass[i] = (m / 3.0) / 3.0;
   int w = indptr[i];
   double diag = 0.0;
@@ -374,6 +601,7 @@ __global__ __launch_bounds__(256) void k_rows(int n, const int32_t* __restrict__
     const int col = ent[a].col;
     double s = 0.0;
     while (a < e && ent[a].col == col) s += ent[a++].val;
+    if (col == i) continue;  // a loop edge of the flipped cover: cancels in L
     if (!diag_done && col > i) {
       diag_pos = w++;
       diag_done = true;
@@ -449,37 +677,76 @@ int pyqsm_pc_laplacian(const double* xyz, int64_t n, int32_t k, double moll, int
     int32_t T = 0;
     PQ_HIP(hipMemcpyAsync(&T, d_tcount + n, 4, hipMemcpyDeviceToHost, c->stream));
     PQ_HIP(hipStreamSynchronize(c->stream));
-    int32_t *d_tris, *d_vcount, *d_cursor, *d_nnzrow;
-    double *d_len, *d_area, *d_blk_sum, *d_blk_slack, *d_eps, *d_mass;
+    int32_t *d_tris, *d_vcount, *d_cursor, *d_nnzrow, *d_fv, *d_fn, *d_bcount, *d_bcursor,
+        *d_claim, *d_cnt;
+    double *d_len, *d_area, *d_blk_sum, *d_blk_slack, *d_eps, *d_mass, *d_fl;
     Entry* d_ent;
+    EdgeRec* d_rec;
+    const int F = 2 * T;  // cover faces
     const int nblk = ceil_div(std::max<int64_t>(T, 1), 256);
     PQ_TRY(c->arena.get(size_t(T) * 3 + 1, &d_tris));
     PQ_TRY(c->arena.get(size_t(T) * 3 + 1, &d_len));
-    PQ_TRY(c->arena.get(size_t(T) + 1, &d_area));
+    PQ_TRY(c->arena.get(size_t(F) + 1, &d_area));
     PQ_TRY(c->arena.get(size_t(nblk), &d_blk_sum));
     PQ_TRY(c->arena.get(size_t(nblk), &d_blk_slack));
     PQ_TRY(c->arena.get(1, &d_eps));
     PQ_TRY(c->arena.get(size_t(n) + 1, &d_vcount));
     PQ_TRY(c->arena.get(size_t(n), &d_cursor));
     PQ_TRY(c->arena.get(size_t(n) + 1, &d_nnzrow));
-    PQ_TRY(c->arena.get(size_t(T) * 6 + 1, &d_ent));
+    PQ_TRY(c->arena.get(size_t(F) * 6 + 1, &d_ent));
     PQ_TRY(c->arena.get(size_t(n), &d_mass));
+    PQ_TRY(c->arena.get(size_t(F) * 3 + 1, &d_fv));
+    PQ_TRY(c->arena.get(size_t(F) * 3 + 1, &d_fl));
+    PQ_TRY(c->arena.get(size_t(F) * 3 + 1, &d_fn));
+    PQ_TRY(c->arena.get(size_t(n) + 1, &d_bcount));
+    PQ_TRY(c->arena.get(size_t(n), &d_bcursor));
+    PQ_TRY(c->arena.get(size_t(T) * 3 + 1, &d_rec));
+    PQ_TRY(c->arena.get(size_t(F) + 1, &d_claim));
+    PQ_TRY(c->arena.get(2, &d_cnt));
     PQ_HIP(hipMemsetAsync(d_vcount, 0, (size_t(n) + 1) * 4, c->stream));
     PQ_HIP(hipMemsetAsync(d_cursor, 0, size_t(n) * 4, c->stream));
     PQ_HIP(hipMemsetAsync(d_nnzrow, 0, (size_t(n) + 1) * 4, c->stream));
+    PQ_HIP(hipMemsetAsync(d_bcount, 0, (size_t(n) + 1) * 4, c->stream));
+    PQ_HIP(hipMemsetAsync(d_bcursor, 0, size_t(n) * 4, c->stream));
     const dim3 gn(ceil_div(n, 256)), gt(nblk), blk(256);
+    const dim3 gf(ceil_div(std::max(F, 1), 256)), gh(ceil_div(std::max(3 * F, 1), 256));
     if (T > 0) {
       hipLaunchKernelGGL(k_compact_tris, gn, blk, 0, c->stream, N, k, d_tri, d_tcount, d_tris);
       hipLaunchKernelGGL(k_tri_lengths, gt, blk, 0, c->stream, T, d_tris, d_xyz, d_len, d_blk_sum,
-                         d_blk_slack, d_vcount);
+                         d_blk_slack);
       PQ_HIP(hipGetLastError());
     }
     hipLaunchKernelGGL(k_mollify_eps, dim3(1), dim3(64), 0, c->stream, T > 0 ? nblk : 0, T,
                        d_blk_sum, d_blk_slack, moll, d_eps);
+    if (T > 0) {
+      // tufted cover: two faces per triangle, glued around every edge
+      hipLaunchKernelGGL(k_cover_init, gt, blk, 0, c->stream, T, d_tris, d_len, d_eps, d_fv, d_fl,
+                         d_bcount);
+      PQ_TRY(exclusive_scan_i32(c, d_bcount, n + 1));
+      hipLaunchKernelGGL(k_edge_scatter, gt, blk, 0, c->stream, T, d_tris, d_bcount, d_bcursor,
+                         d_rec);
+      hipLaunchKernelGGL(k_glue, gn, blk, 0, c->stream, N, d_bcount, d_rec, d_fn);
+      PQ_HIP(hipGetLastError());
+      // intrinsic Delaunay flips: rounds of conflict-free flips until none is left
+      ProfScope pf(c, "lap_flips");
+      for (int round = 0; round < kMaxFlipRounds; ++round) {
+        PQ_HIP(hipMemsetAsync(d_claim, 0, (size_t(F) + 1) * 4, c->stream));
+        PQ_HIP(hipMemsetAsync(d_cnt, 0, 8, c->stream));
+        hipLaunchKernelGGL(k_flip_claim, gh, blk, 0, c->stream, 3 * F, d_fl, d_fn, d_claim, d_cnt);
+        hipLaunchKernelGGL(k_flip_apply, gh, blk, 0, c->stream, 3 * F, d_fv, d_fl, d_fn, d_claim,
+                           d_cnt + 1);
+        PQ_HIP(hipGetLastError());
+        int32_t hc[2] = {0, 0};
+        PQ_HIP(hipMemcpyAsync(hc, d_cnt, 8, hipMemcpyDeviceToHost, c->stream));
+        PQ_HIP(hipStreamSynchronize(c->stream));
+        if (hc[0] == 0 || hc[1] == 0) break;  // nothing left to flip (or nothing could be flipped)
+      }
+      hipLaunchKernelGGL(k_cover_vcount, gf, blk, 0, c->stream, F, d_fv, d_vcount);
+    }
     PQ_TRY(exclusive_scan_i32(c, d_vcount, n + 1));  // row_start of the contributions
     if (T > 0) {
-      hipLaunchKernelGGL(k_tri_weights, gt, blk, 0, c->stream, T, d_tris, d_len, d_eps, d_vcount,
-                         d_cursor, d_ent, d_area);
+      hipLaunchKernelGGL(k_cover_weights, gf, blk, 0, c->stream, F, d_fv, d_fl, d_vcount, d_cursor,
+                         d_ent, d_area);
       PQ_HIP(hipGetLastError());
     }
     hipLaunchKernelGGL(k_rows<0>, gn, blk, 0, c->stream, N, d_vcount, d_ent, d_area, d_nnzrow,
