@@ -188,6 +188,17 @@ int pyqsm_spmv3(const int32_t* indptr, const int32_t* indices, const double* val
 int pyqsm_clamp(double* pts, int64_t n, const double lo[3], const double hi[3],
                 int32_t device);
 
+/* ---- farthest-point down-sampling ---------------------------------------- */
+/*
+ * Stands in for open3d PointCloud.farthest_point_down_sample(num_samples) as
+ * called by extract_topology at pyQSM/geometry/skeletonize.py:127-132.
+ *   out_idx i32 [num_samples]: indices in selection order, the first being
+ *   start_index (Open3D starts at 0); each next one is the point farthest from
+ *   everything selected so far (squared distance in fp64, lowest index on ties).
+ */
+int pyqsm_fps(const double* xyz, int64_t n, int64_t num_samples, int64_t start_index,
+              int32_t* out_idx, int32_t device);
+
 /* ---- point-cloud Laplacian ---------------------------------------------- */
 /*
  * Stands in for robust_laplacian.point_cloud_laplacian(pts, mollify_factor,

@@ -345,3 +345,23 @@ def point_cloud_laplacian(points, n_neighbors=30, mollify_factor=1e-5):
         for q in (ip, ix, dv):
             lib.orc_free(q)
     return csr_matrix((data, indices, indptr), shape=(n, n)), mass
+
+
+# --------------------------------------------------------------------------
+# Farthest-point sampling (open3d PointCloud.farthest_point_down_sample,
+# pyQSM/geometry/skeletonize.py:132). Open3D is absent: restated from its
+# documented algorithm (start at index 0, keep the running minimum of squared
+# distances, pick the arg-max, first index on ties). PARITY UNPINNED.
+
+def farthest_point_sampling(points, num_samples, start_index=0):
+    pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+    dist = np.full(len(pts), np.inf)
+    out = np.empty(num_samples, dtype=np.int32)
+    sel = int(start_index)
+    for s in range(num_samples):
+        out[s] = sel
+        t = pts - pts[sel]
+        d = (t[:, 0] * t[:, 0] + t[:, 1] * t[:, 1]) + t[:, 2] * t[:, 2]
+        dist = np.minimum(dist, d)
+        sel = int(np.argmax(dist))          # first maximum
+    return out

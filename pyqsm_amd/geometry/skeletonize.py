@@ -204,3 +204,173 @@ def extract_skeleton(pcd, moll=_SK["moll"], n_neighbors=_SK["n_neighbors"],
 
 
 skeletonize = extract_skeleton   # BASELINE.json north_star name
+
+
+# --------------------------------------------------------------------------------------
+# After the contraction: down-sample, span, simplify (skeletonize.py:36-146).
+# Farthest-point sampling and the kNN search run on the GPU; the minimum spanning tree
+# (SciPy, which is what mistree calls) and the degree-2 collapsing (networkx, as in the
+# reference) are small host-side graph steps.
+
+class LineSet:
+    """points float64 [m,3] + lines int [e,2] (stands in for open3d.geometry.LineSet)."""
+
+    def __init__(self, points, lines):
+        self.points = np.asarray(points, dtype=np.float64).reshape(-1, 3)
+        self.lines = np.asarray(lines, dtype=np.int64).reshape(-1, 2)
+
+
+def farthest_point_down_sample(points, num_samples: int, device: int = 0):
+    """Indices and coordinates of ``num_samples`` points chosen like Open3D's
+    ``PointCloud.farthest_point_down_sample`` (start at point 0, then always the point
+    farthest from everything chosen so far; skeletonize.py:132)."""
+    pts = as_points(points)
+    idx = hip.fps(pts, num_samples, 0, device=device)
+    return idx, pts[idx]
+
+
+def extract_skeletal_graph(skeletal_points: np.ndarray, graph_k_n, device: int = 0):
+    """skeletonize.py:36-55: minimum spanning tree of the k-nearest-neighbour graph
+    (mistree.construct_mst = sklearn kneighbors_graph + SciPy minimum_spanning_tree) as
+    a networkx graph whose nodes carry ``pos``. Returns ``(mst_graph, rx_graph)``;
+    rustworkx is optional and ``rx_graph`` is None when it is not installed."""
+    import networkx as nx
+    from scipy.sparse import csr_matrix
+    from scipy.sparse.csgraph import minimum_spanning_tree
+    pts = as_points(skeletal_points)
+    n = len(pts)
+    k = int(min(graph_k_n, max(n - 1, 1)))
+    idx, d2 = hip.knn(pts, k, True, device=device)
+    valid = idx < n
+    rows = np.repeat(np.arange(n), k)[valid.ravel()]
+    cols = idx.ravel()[valid.ravel()]
+    dist = np.sqrt(d2.ravel()[valid.ravel()])
+    graph = csr_matrix((dist, (rows, cols)), shape=(n, n))
+    mst = minimum_spanning_tree(graph).tocoo()
+    edges = np.stack([mst.row, mst.col], axis=1)
+    mst_graph = nx.Graph(edges.tolist())
+    mst_graph.add_nodes_from(range(n))
+    for i in range(n):
+        mst_graph.nodes[i]["pos"] = pts[i].T
+    rx_graph = None
+    try:
+        import rustworkx as rx
+        rx_graph = rx.PyGraph()
+        for i in range(n):
+            rx_graph.add_node({"pos": pts[i].T})
+        rx_graph.add_edges_from([(int(a), int(b), tuple(pts[a] - pts[b])) for a, b in edges])
+    except ModuleNotFoundError:
+        pass
+    return mst_graph, rx_graph
+
+
+def simplify_graph(G):
+    """skeletonize.py:57-98: remove every node of degree 2 and fuse its two edges; the
+    fused edge remembers the removed nodes in its ``data`` list. Returns
+    ``(graph, kept_node_positions, kept_node_indices)``."""
+    g = G.copy()
+    keept_node_pos = []
+    keept_node_idx = []
+    while any(degree == 2 for _, degree in g.degree):
+        keept_node_pos = []
+        keept_node_idx = []
+        g0 = g.copy()
+        for node, degree in g.degree():
+            if degree == 2:
+                edges = list(g0.edges(node, data=True))
+                a0, b0, data0 = edges[0]
+                a1, b1, data1 = edges[1]
+                e0 = a0 if a0 != node else b0
+                e1 = a1 if a1 != node else b1
+                edata = data0.get("data", []) + data1.get("data", [])
+                edata.append(node)
+                g0.remove_node(node)
+                g0.add_edge(e0, e1, data=edata)
+            else:
+                keept_node_pos.append(g.nodes[node]["pos"])
+                keept_node_idx.append(node)
+        g = g0
+    if not keept_node_idx:                      # nothing was simplified: keep every node
+        keept_node_idx = list(g.nodes)
+        keept_node_pos = [g.nodes[v]["pos"] for v in keept_node_idx]
+    return g, keept_node_pos, keept_node_idx
+
+
+def simplify_and_update(graph):
+    """skeletonize.py:100-111: simplify, then relabel the surviving nodes 0..m-1 in the
+    order their positions are listed."""
+    import networkx as nx
+    G_simplified, node_pos, node_idx = simplify_graph(graph)
+    skeleton_cleaned_points = np.vstack(node_pos) if node_pos else np.zeros((0, 3))
+    mapping = {node: i for i, node in enumerate(node_idx) if node in G_simplified}
+    return nx.relabel_nodes(G_simplified, mapping), skeleton_cleaned_points, mapping
+
+
+def extract_topology(contracted, graph_k_n=_SK["graph_k_n"], device: int = 0):
+    """skeletonize.py:113-146. ``contracted`` is the contracted cloud (array or object
+    with ``.points``). Returns ``(topology, topology_graph, skeleton, skeleton_points,
+    skeleton_graph, rx_graph, mapping)`` like the reference."""
+    pts = as_points(contracted)
+    # artefacts collapsed onto the origin (:118-124)
+    norms = np.linalg.norm(pts, axis=1)
+    near = int(np.argmin(norms))
+    if norms[near] <= 0.01:
+        keep = np.linalg.norm(pts - pts[near], axis=1) > 0.01
+        pts = pts[keep]
+    fps_points = max(int(pts.shape[0] * 0.1), 15)                       # :128-129
+    fps_points = min(fps_points, pts.shape[0])
+    log.info(f"down sampling contracted, starting with {len(pts)} points, taking {fps_points}")
+    _, skeleton_points = farthest_point_down_sample(pts, fps_points, device=device)
+    skeleton = PointCloud(skeleton_points)
+    skeleton_graph, rx_graph = extract_skeletal_graph(skeleton_points, graph_k_n, device=device)
+    topology_graph, topology_points, mapping = simplify_and_update(skeleton_graph)
+    topology = LineSet(topology_points, list(topology_graph.edges()))
+    return (topology, topology_graph, skeleton, skeleton_points, skeleton_graph, rx_graph,
+            mapping)
+
+
+
+def skeleton_to_QSM(topology, topology_graph, total_point_shift, test=True):
+    """skeletonize.py:375-441: one cylinder per topology edge, from the edge's end
+    points, with radius = mean contraction distance of the vertices that were fused into
+    that edge (``data`` lists of :func:`simplify_graph`; indices are used exactly as the
+    reference uses them, i.e. directly into ``total_point_shift``).
+
+    Returns ``(all_cyl_pcd, cyls, cyl_objects, radii)``: the union of the sampled cylinder
+    surfaces, one point cloud per cylinder, the :class:`Cylinder` objects and the radii.
+    Sampling follows skspatial's ``Cylinder.to_points(n_angles=20).round(3).unique()``
+    in spirit (scikit-spatial is not installable here: 100 steps along the axis)."""
+    try:
+        from .cloud import Cylinder
+    except ImportError:
+        from pyqsm_amd.geometry.cloud import Cylinder
+    edge_to_orig = {}
+    for a, b, d in topology_graph.edges(data=True):
+        edge_to_orig[(a, b)] = d.get("data")
+        edge_to_orig[(b, a)] = d.get("data")
+    points = np.asarray(topology.points)
+    lines = np.asarray(topology.lines)
+    contraction_dist = np.linalg.norm(np.asarray(total_point_shift), axis=1)
+    cyls, cyl_objects, radii = [], [], []
+    for line in lines:
+        start, end = points[line[0]], points[line[1]]
+        orig = edge_to_orig.get((int(line[0]), int(line[1])))
+        if not orig:
+            continue                                     # an edge that absorbed no vertex
+        radius = float(np.mean(contraction_dist[np.asarray(orig, dtype=np.int64)]))
+        axis = end - start
+        height = float(np.linalg.norm(axis))
+        if height == 0:
+            continue
+        cyl = Cylinder((start + end) / 2.0, radius, height, axis)
+        u, v = cyl._frame()
+        ang = np.linspace(0.0, 2.0 * np.pi, 20, endpoint=False)
+        along = np.linspace(-height / 2.0, height / 2.0, 100)
+        ring = radius * (np.cos(ang)[:, None] * u + np.sin(ang)[:, None] * v)
+        pts = (cyl.center + ring[None, :, :] + along[:, None, None] * cyl.axis).reshape(-1, 3)
+        pts = np.unique(pts.round(3), axis=0)
+        cyls.append(PointCloud(pts))
+        cyl_objects.append(cyl)
+        radii.append(radius)
+    all_pts = np.concatenate([c.points for c in cyls]) if cyls else np.zeros((0, 3))
+    return PointCloud(all_pts), cyls, cyl_objects, radii

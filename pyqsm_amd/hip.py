@@ -306,6 +306,17 @@ def clamp(pts: np.ndarray, lo, hi, device: int = 0) -> np.ndarray:
     return pts
 
 
+# ---------------------------------------------------------------- down-sampling
+
+def fps(points, num_samples: int, start_index: int = 0, device: int = 0) -> np.ndarray:
+    """Farthest-point sampling: int32 indices in selection order."""
+    pts = _points(points)
+    out = np.empty(int(num_samples), dtype=np.int32)
+    check(_lib.load().pyqsm_fps(_p(pts), pts.shape[0], int(num_samples), int(start_index),
+                                _p(out), int(device)))
+    return out
+
+
 # ---------------------------------------------------------------- Laplacian
 
 def pc_laplacian(points, k: int = 30, moll: float = 1e-5, device: int = 0):
