@@ -83,30 +83,39 @@ __device__ __forceinline__ Tile wave_tile(int p0, int n, Stencil st, int ncell,
   const int plast = p0 + 63 < n ? p0 + 63 : n - 1;
   const int c_first = __builtin_amdgcn_readfirstlane(cell_of[p0]);
   const int c_last = __builtin_amdgcn_readfirstlane(cell_of[plast]);
-  t.total = 0;
-  int w = 0, prev_hi = -1;
-  // offsets ascend with (dz, dy), so the intervals come sorted by their lower end;
-  // a wave that spans more than a grid row makes neighbouring intervals overlap,
-  // and each is clipped against what the previous ones already cover
+  // the nine intervals, sorted by lower end (they already are unless the grid has
+  // fewer than three rows), then clipped against what the earlier ones cover: a wave
+  // that spans more than a grid row makes neighbouring intervals overlap
+  int lo[9], hi[9];
+  int w = 0;
   for (int dz = -1; dz <= 1; ++dz)
     for (int dy = -1; dy <= 1; ++dy) {
       const int o = dy * st.nx + dz * st.nxy;
-      int lo = c_first + o - 1, hi = c_last + o + 1;
-      lo = lo < 0 ? 0 : lo;
-      hi = hi > ncell - 1 ? ncell - 1 : hi;
-      lo = lo <= prev_hi ? prev_hi + 1 : lo;
-      if (lo <= hi) {
-        t.qb[w] = start[lo];
-        t.qe[w] = start[hi + 1];
-        prev_hi = hi;
-      } else {
-        t.qb[w] = t.qe[w] = 0;
+      int a = c_first + o - 1, b = c_last + o + 1;
+      a = a < 0 ? 0 : a;
+      b = b > ncell - 1 ? ncell - 1 : b;
+      int k = w++;
+      while (k > 0 && lo[k - 1] > a) {
+        lo[k] = lo[k - 1];
+        hi[k] = hi[k - 1];
+        --k;
       }
-      t.qb[w] = __builtin_amdgcn_readfirstlane(t.qb[w]);
-      t.qe[w] = __builtin_amdgcn_readfirstlane(t.qe[w]);
-      t.total += t.qe[w] - t.qb[w];
-      ++w;
+      lo[k] = a;
+      hi[k] = b;
     }
+  t.total = 0;
+  int prev_hi = -1;
+  for (int r = 0; r < 9; ++r) {
+    const int a = lo[r] <= prev_hi ? prev_hi + 1 : lo[r];
+    if (a <= hi[r]) {
+      t.qb[r] = __builtin_amdgcn_readfirstlane(start[a]);
+      t.qe[r] = __builtin_amdgcn_readfirstlane(start[hi[r] + 1]);
+      prev_hi = hi[r];
+    } else {
+      t.qb[r] = t.qe[r] = 0;
+    }
+    t.total += t.qe[r] - t.qb[r];
+  }
   return t;
 }
 
@@ -231,6 +240,14 @@ __global__ __launch_bounds__(256) void k_union(int n, Stencil st, const int32_t*
     }
   })
 }
+
+// (Measured alternatives for this kernel, MI355X, 1 M-point forest, per launch:
+//  per-lane walk above 1.15 ms; candidates staged through LDS like k_core_tiled with
+//  per-lane unite 1.4 ms; the same plus in-wave component labels so that one lane per
+//  local component talks to the global forest 1.3 ms. 91 % of the wave cycles are
+//  memory waits in the find/CAS chains themselves (profiles/r01_dbscan_sq_counters.csv),
+//  and SIMT serialisation of divergent unite() calls costs the tiled forms more than
+//  the cheaper traversal saves. The simple form stays.)
 
 // root[p] for core points, then the smallest original index of each component.
 // A cluster of 50 k points would send 50 k atomicMin to one address (0.77 ms in
