@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[4] on one GPU, scaled by --scale: scan -> DBSCAN -> per-tree
+Laplacian contraction -> RANSAC circles on z-slices -> canopy light simulation.
+
+    python examples/config5_pipeline.py [--scale 0.04]     # 0.04 -> 200 k points, 2 M rays
+
+Every stage goes through the pyQSM-named wrappers (cluster_DBSCAN, extract_skeleton,
+fit_shape_RANSAC, cast_rays), i.e. through the ctypes C-ABI into the HIP kernels; one JSON
+line with the per-stage times is printed. At --scale 1 this is the 5 M-point / 50 M-ray
+configuration; the ray stage is the only one that shards over several GPUs (bench.py)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pyqsm_amd import _lib, synth  # noqa: E402
+from pyqsm_amd.geometry.skeletonize import extract_skeleton  # noqa: E402
+from pyqsm_amd.math_utils.fit import cluster_DBSCAN, draw_samples, fit_shape_RANSAC  # noqa: E402
+from pyqsm_amd.set_config import config  # noqa: E402
+from pyqsm_amd.viz.ray_casting import cast_rays  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scale", type=float, default=0.04)
+    ap.add_argument("--skeleton-iters", type=int, default=3)
+    ap.add_argument("--max-trees", type=int, default=2, help="trees that get skeletonised")
+    args = ap.parse_args()
+    _lib.require_gpu(0)
+    n_points = max(50_000, int(5_000_000 * args.scale))
+    n_rays_per_angle = max(100_000, int(10_000_000 * args.scale))
+    n_tris = max(20_000, int(500_000 * min(1.0, args.scale * 5)))
+    out = {"points": n_points, "rays": 5 * n_rays_per_angle, "tris": n_tris}
+
+    pts = synth.forest(n_points, seed=0)
+    t0 = time.perf_counter()
+    labels, idxs, noise = cluster_DBSCAN(np.arange(len(pts)), pts, config["dbscan"]["epsilon"],
+                                         config["dbscan"]["min_neighbors"])
+    out["dbscan_s"] = time.perf_counter() - t0
+    out["clusters"] = len(idxs)
+    idxs = sorted(idxs, key=len, reverse=True)
+
+    t0 = time.perf_counter()
+    shifts = []
+    for tree in idxs[: args.max_trees]:
+        cloud = pts[tree]
+        contracted, total_shift, steps = extract_skeleton(cloud, max_iter=args.skeleton_iters,
+                                                          termination_ratio=0.0)
+        shifts.append(float(np.linalg.norm(total_shift, axis=1).mean()))
+    out["skeleton_s"] = time.perf_counter() - t0
+    out["skeleton_trees"] = len(shifts)
+    out["mean_contraction_m"] = shifts
+
+    t0 = time.perf_counter()
+    fits = 0
+    radii = []
+    for tree in idxs[: max(args.max_trees, 4)]:
+        cloud = pts[tree]
+        for z0 in np.arange(0.5, 5.5, 0.5):                 # 0.5 m slices of the stem
+            sl = cloud[(cloud[:, 2] >= z0) & (cloud[:, 2] < z0 + 0.5)]
+            sl = sl[np.hypot(sl[:, 0] - np.median(sl[:, 0]), sl[:, 1] - np.median(sl[:, 1])) < 0.6]
+            if len(sl) < 50:
+                continue
+            samples = draw_samples(len(sl), 1000, seed=2)
+            mesh, _, inl, r, axis = fit_shape_RANSAC(pts=sl.copy(), shape="circle", threshold=0.04,
+                                                     max_radius=0.3 * 1.75, samples=samples)
+            if mesh is not None:
+                fits += 1
+                radii.append(float(r))
+    out["ransac_s"] = time.perf_counter() - t0
+    out["ransac_fits"] = fits
+    out["ransac_median_radius_m"] = float(np.median(radii)) if radii else None
+
+    verts, tris = synth.canopy_mesh(n_tris)
+    t0 = time.perf_counter()
+    lit = []
+    for az in (45.0, 90.0, 135.0, 180.0, 225.0):
+        rays = synth.sun_rays(verts, n_rays_per_angle, elevation_deg=60.0, azimuth_deg=az)
+        ans = cast_rays((verts, tris), rays=rays)
+        lit.append(float(ans["hit"].mean()))
+    out["rays_s"] = time.perf_counter() - t0
+    out["intercepted_fraction"] = lit
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
