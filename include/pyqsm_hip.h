@@ -188,6 +188,26 @@ int pyqsm_spmv3(const int32_t* indptr, const int32_t* indices, const double* val
 int pyqsm_clamp(double* pts, int64_t n, const double lo[3], const double hi[3],
                 int32_t device);
 
+/* ---- fixed-radius queries -------------------------------------------------- */
+/*
+ * All points within `radius` of one centre (inclusive, d <= radius), ascending
+ * indices: scipy KDTree(points).query_ball_point(center, r) as called at
+ * pyQSM/utils/lib_integration.py:114-115 (find_neighbors_in_ball).
+ *   out_idx i64 [n] capacity; *count = number written.
+ */
+int pyqsm_ball_query(const double* xyz, int64_t n, const double center[3], double radius,
+                     int64_t* out_idx, int64_t* count, int32_t device);
+/*
+ * Union of the (at most k_cap nearest) neighbours within `radius` (strict,
+ * d < radius) of every query point: the index set produced by
+ * scipy KDTree(src).query(qry, k, distance_upper_bound=radius) at
+ * pyQSM/geometry/reconstruction.py:238-244 and pyQSM/tree_isolation.py:126-131.
+ *   mark u8 [n]: 1 for every source point some query selects;
+ *   counts i32 [m]: neighbours each query selects (<= k_cap).
+ */
+int pyqsm_radius_mark(const double* src, int64_t n, const double* qry, int64_t m, double radius,
+                      int32_t k_cap, uint8_t* mark, int32_t* counts, int32_t device);
+
 /* ---- farthest-point down-sampling ---------------------------------------- */
 /*
  * Stands in for open3d PointCloud.farthest_point_down_sample(num_samples) as

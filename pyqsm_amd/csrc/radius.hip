@@ -1,0 +1,214 @@
+// radius.hip — fixed-radius queries on gfx950.
+//
+//   pyqsm_ball_query    all points within r of ONE centre: what
+//                       scipy KDTree(points).query_ball_point(center, r) returns at
+//                       pyQSM/utils/lib_integration.py:114-115 (find_neighbors_in_ball,
+//                       called once per branch segment by qsm_generation.sphere_step;
+//                       the reference rebuilds the KD-tree of the whole cloud every
+//                       call). One HBM pass: 24 B per point, inclusive d <= r.
+//   pyqsm_radius_mark   for a set of query points, the union of their (up to k nearest)
+//                       neighbours within a distance bound: the index set that
+//                       KDTree(src).query(query, k, distance_upper_bound=dist) yields at
+//                       pyQSM/geometry/reconstruction.py:238-244 and
+//                       pyQSM/tree_isolation.py:126-131,207-209. Strict d < dist, like
+//                       cKDTree. The source cloud is binned into cells of edge `dist`;
+//                       one lane per query walks its 27 cells. When more than k points
+//                       lie inside the bound, the k-th smallest squared distance is found
+//                       exactly by bisection on its bit pattern and only those are marked.
+// Squared distances are fp64, ((dx*dx)+dy*dy)+dz*dz, the accumulation of cKDTree.
+#include "grid.hpp"
+
+#include <cmath>
+
+namespace pyqsm {
+
+__device__ __forceinline__ double sqd(double ax, double ay, double az, double bx, double by,
+                                      double bz) {
+  double t0 = ax - bx, t1 = ay - by, t2 = az - bz;
+  double d = t0 * t0;
+  d = d + t1 * t1;
+  d = d + t2 * t2;
+  return d;
+}
+
+__global__ __launch_bounds__(256) void k_ball_flags(int64_t n, const double* __restrict__ xyz,
+                                                    double cx, double cy, double cz, double r2,
+                                                    int32_t* __restrict__ flags) {
+  int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+  if (i > n) return;
+  flags[i] = i < n && sqd(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], cx, cy, cz) <= r2;
+}
+
+__global__ __launch_bounds__(256) void k_ball_compact(int64_t n, const int32_t* __restrict__ pos,
+                                                      int64_t* __restrict__ out) {
+  int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+  if (i >= n) return;
+  if (pos[i + 1] != pos[i]) out[pos[i]] = i;
+}
+
+struct RGrid {
+  double minx, miny, minz, inv;
+  int nx, ny, nz;
+};
+
+// MODE 0: count of source points with d2 < r2.  MODE 1: count with d2 <= tau.
+// MODE 2: mark every source point with d2 < bound (bound = r2, or tau plus ties).
+template <int MODE>
+__device__ __forceinline__ int walk(const RGrid& g, const int32_t* __restrict__ start,
+                                    const int32_t* __restrict__ order,
+                                    const double* __restrict__ sx, const double* __restrict__ sy,
+                                    const double* __restrict__ sz, double x, double y, double z,
+                                    double r2, double tau, int budget, uint8_t* __restrict__ mark) {
+  int cx = int(floor((x - g.minx) * g.inv)) + 1;
+  int cy = int(floor((y - g.miny) * g.inv)) + 1;
+  int cz = int(floor((z - g.minz) * g.inv)) + 1;
+  // queries may lie outside the source grid: more than one cell away nothing is in range
+  if (cx < 0 || cy < 0 || cz < 0 || cx > g.nx - 1 || cy > g.ny - 1 || cz > g.nz - 1) return 0;
+  int cnt = 0;
+  for (int dz = -1; dz <= 1; ++dz) {
+    const int zz = cz + dz;
+    if (zz < 0 || zz >= g.nz) continue;
+    for (int dy = -1; dy <= 1; ++dy) {
+      const int yy = cy + dy;
+      if (yy < 0 || yy >= g.ny) continue;
+      const int x0 = cx - 1 < 0 ? 0 : cx - 1, x1 = cx + 1 >= g.nx ? g.nx - 1 : cx + 1;
+      const int row = (zz * g.ny + yy) * g.nx;
+      for (int q = start[row + x0]; q < start[row + x1 + 1]; ++q) {
+        const double d = sqd(x, y, z, sx[q], sy[q], sz[q]);
+        if (MODE == 0) cnt += d < r2;
+        if (MODE == 1) cnt += d < r2 && d <= tau;
+        if (MODE == 2) {
+          if (d < r2 && d < tau) {
+            mark[order[q]] = 1;
+          } else if (d < r2 && d == tau && cnt < budget) {  // ties at the k-th distance
+            mark[order[q]] = 1;
+            ++cnt;
+          }
+        }
+      }
+    }
+  }
+  return cnt;
+}
+
+__global__ __launch_bounds__(256) void k_radius_mark(int m, const double* __restrict__ qry,
+                                                     RGrid g, const int32_t* __restrict__ start,
+                                                     const int32_t* __restrict__ order,
+                                                     const double* __restrict__ sx,
+                                                     const double* __restrict__ sy,
+                                                     const double* __restrict__ sz, double r2,
+                                                     int k, uint8_t* __restrict__ mark,
+                                                     int32_t* __restrict__ counts) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= m) return;
+  const double x = qry[3 * i], y = qry[3 * i + 1], z = qry[3 * i + 2];
+  const int c = walk<0>(g, start, order, sx, sy, sz, x, y, z, r2, 0.0, 0, mark);
+  counts[i] = c < k ? c : k;
+  if (c == 0) return;
+  double tau = __builtin_inf();
+  int budget = 0;
+  if (c > k) {
+    // k-th smallest squared distance: bisection on the (order-preserving) bit pattern
+    unsigned long long lo = 0, hi = (unsigned long long)__double_as_longlong(r2);
+    while (lo < hi) {  // smallest t with #{d2 <= t} >= k
+      const unsigned long long mid = lo + ((hi - lo) >> 1);
+      const double t = __longlong_as_double((long long)mid);
+      if (walk<1>(g, start, order, sx, sy, sz, x, y, z, r2, t, 0, mark) >= k) hi = mid;
+      else lo = mid + 1;
+    }
+    tau = __longlong_as_double((long long)lo);
+    // points strictly below tau are all taken; ties at tau fill what is left of k
+    const double below = lo == 0 ? -1.0 : __longlong_as_double((long long)(lo - 1));
+    const int n_below = lo == 0 ? 0 : walk<1>(g, start, order, sx, sy, sz, x, y, z, r2, below, 0, mark);
+    budget = k - n_below;
+  }
+  (void)walk<2>(g, start, order, sx, sy, sz, x, y, z, r2, tau, budget, mark);
+}
+
+}  // namespace pyqsm
+
+using namespace pyqsm;
+
+extern "C" {
+
+int pyqsm_ball_query(const double* xyz, int64_t n, const double center[3], double radius,
+                     int64_t* out_idx, int64_t* count, int32_t device) {
+  if (n < 0) return fail(PYQSM_EINVAL, "negative size");
+  if (count) *count = 0;
+  if (n == 0) return 0;
+  if (!xyz || !center || !out_idx || !count)
+    return fail(PYQSM_EINVAL, "pyqsm_ball_query: NULL pointer");
+  if (!(radius >= 0)) return fail(PYQSM_EINVAL, "radius must be >= 0");
+  if (n > 0x7FFFFF00LL) return fail(PYQSM_ERANGE, "more than 2^31 points per call");
+  Ctx* c = ctx_for(device);
+  if (!c) return PYQSM_ENODEV;
+  std::lock_guard<std::mutex> lk(c->mu);
+  c->arena.reset();
+  double* d_xyz;
+  int32_t* d_flags;
+  int64_t* d_out;
+  PQ_TRY(c->arena.get(size_t(n) * 3, &d_xyz));
+  PQ_TRY(c->arena.get(size_t(n) + 1, &d_flags));
+  PQ_TRY(c->arena.get(size_t(n), &d_out));
+  PQ_HIP(hipMemcpyAsync(d_xyz, xyz, size_t(n) * 24, hipMemcpyHostToDevice, c->stream));
+  {
+    ProfScope ps(c, "ball_query");
+    hipLaunchKernelGGL(k_ball_flags, dim3(ceil_div(n + 1, 256)), dim3(256), 0, c->stream, n, d_xyz,
+                       center[0], center[1], center[2], radius * radius, d_flags);
+    PQ_TRY(exclusive_scan_i32(c, d_flags, n + 1));
+    hipLaunchKernelGGL(k_ball_compact, dim3(ceil_div(n, 256)), dim3(256), 0, c->stream, n, d_flags,
+                       d_out);
+    PQ_HIP(hipGetLastError());
+  }
+  int32_t total = 0;
+  PQ_HIP(hipMemcpyAsync(&total, d_flags + n, 4, hipMemcpyDeviceToHost, c->stream));
+  PQ_HIP(hipStreamSynchronize(c->stream));
+  if (total)
+    PQ_HIP(hipMemcpyAsync(out_idx, d_out, size_t(total) * 8, hipMemcpyDeviceToHost, c->stream));
+  PQ_HIP(hipStreamSynchronize(c->stream));
+  *count = total;
+  return 0;
+}
+
+int pyqsm_radius_mark(const double* src, int64_t n, const double* qry, int64_t m, double radius,
+                      int32_t k_cap, uint8_t* mark, int32_t* counts, int32_t device) {
+  if (n < 0 || m < 0) return fail(PYQSM_EINVAL, "negative size");
+  if (n > 0 && (!src || !mark)) return fail(PYQSM_EINVAL, "pyqsm_radius_mark: NULL pointer");
+  if (m > 0 && (!qry || !counts)) return fail(PYQSM_EINVAL, "pyqsm_radius_mark: NULL pointer");
+  if (!(radius > 0) || !std::isfinite(radius)) return fail(PYQSM_EINVAL, "radius must be positive");
+  if (k_cap <= 0) return fail(PYQSM_EINVAL, "k must be positive");
+  if (n > 0) memset(mark, 0, size_t(n));
+  if (m > 0) memset(counts, 0, size_t(m) * 4);
+  if (n == 0 || m == 0) return 0;
+  if (m > 0x7FFFFF00LL) return fail(PYQSM_ERANGE, "more than 2^31 query points per call");
+  Ctx* c = ctx_for(device);
+  if (!c) return PYQSM_ENODEV;
+  std::lock_guard<std::mutex> lk(c->mu);
+  c->arena.reset();
+  double *d_src, *d_qry;
+  uint8_t* d_mark;
+  int32_t* d_counts;
+  PQ_TRY(c->arena.get(size_t(n) * 3, &d_src));
+  PQ_TRY(c->arena.get(size_t(m) * 3, &d_qry));
+  PQ_TRY(c->arena.get(size_t(n), &d_mark));
+  PQ_TRY(c->arena.get(size_t(m), &d_counts));
+  PQ_HIP(hipMemcpyAsync(d_src, src, size_t(n) * 24, hipMemcpyHostToDevice, c->stream));
+  PQ_HIP(hipMemcpyAsync(d_qry, qry, size_t(m) * 24, hipMemcpyHostToDevice, c->stream));
+  PQ_HIP(hipMemsetAsync(d_mark, 0, size_t(n), c->stream));
+  DevGrid g;
+  PQ_TRY(build_grid(c, d_src, n, radius * (1.0 + 1.0 / 1048576.0), int64_t(1) << 28, &g));
+  RGrid rg{g.minx, g.miny, g.minz, g.inv_cell, g.nx, g.ny, g.nz};
+  {
+    ProfScope ps(c, "radius_mark");
+    hipLaunchKernelGGL(k_radius_mark, dim3(ceil_div(m, 256)), dim3(256), 0, c->stream, int(m), d_qry,
+                       rg, g.start, g.order, g.sx, g.sy, g.sz, radius * radius, k_cap, d_mark,
+                       d_counts);
+    PQ_HIP(hipGetLastError());
+  }
+  PQ_HIP(hipMemcpyAsync(mark, d_mark, size_t(n), hipMemcpyDeviceToHost, c->stream));
+  PQ_HIP(hipMemcpyAsync(counts, d_counts, size_t(m) * 4, hipMemcpyDeviceToHost, c->stream));
+  PQ_HIP(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+}  // extern "C"

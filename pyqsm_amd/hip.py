@@ -306,6 +306,31 @@ def clamp(pts: np.ndarray, lo, hi, device: int = 0) -> np.ndarray:
     return pts
 
 
+# ---------------------------------------------------------------- radius queries
+
+def ball_query(points, center, radius: float, device: int = 0) -> np.ndarray:
+    """Ascending int64 indices of the points with |p - center| <= radius."""
+    pts = _points(points)
+    ctr = np.ascontiguousarray(center, dtype=np.float64).reshape(3)
+    out = np.empty(max(pts.shape[0], 1), dtype=np.int64)
+    cnt = i64(0)
+    check(_lib.load().pyqsm_ball_query(_p(pts), pts.shape[0], _p(ctr), float(radius), _p(out),
+                                       ctypes.byref(cnt), int(device)))
+    return out[:cnt.value].copy()
+
+
+def radius_mark(src, queries, radius: float, k: int = 500, device: int = 0):
+    """(mask bool [n], counts int32 [m]): source points that are among the k nearest
+    neighbours within `radius` (strict) of at least one query point."""
+    s = _points(src)
+    q = _points(queries)
+    mark = np.zeros(s.shape[0], dtype=np.uint8)
+    counts = np.zeros(q.shape[0], dtype=np.int32)
+    check(_lib.load().pyqsm_radius_mark(_p(s), s.shape[0], _p(q), q.shape[0], float(radius),
+                                        int(k), _p(mark), _p(counts), int(device)))
+    return mark.astype(bool), counts
+
+
 # ---------------------------------------------------------------- down-sampling
 
 def fps(points, num_samples: int, start_index: int = 0, device: int = 0) -> np.ndarray:

@@ -1,0 +1,62 @@
+"""Fixed-radius queries against SciPy's cKDTree — the engine the reference calls at
+lib_integration.py:114-115 and reconstruction.py:238-244 (pinned: SciPy runs live here)."""
+import numpy as np
+import pytest
+from scipy.spatial import cKDTree
+
+from pyqsm_amd import hip, synth
+from pyqsm_amd.geometry.reconstruction import get_neighbors_kdtree
+from pyqsm_amd.utils.lib_integration import find_neighbors_in_ball, get_neighbors_in_tree
+
+pytestmark = pytest.mark.gpu
+
+
+def _kdtree_union(src, qry, dist, k):
+    d, i = cKDTree(src).query(qry, k=k, distance_upper_bound=dist)
+    i = np.atleast_2d(i.reshape(len(qry), -1))
+    return np.unique(i[i < len(src)]), (i < len(src)).sum(axis=1)
+
+
+@pytest.mark.parametrize("dist,k", [(0.05, 500), (0.3, 500), (0.3, 40), (0.15, 7)])
+def test_radius_mark_matches_ckdtree(gpu, dist, k):
+    src = synth.forest(30_000, seed=1)
+    qry = synth.forest(30_000, seed=1)[::37] + [0.01, -0.02, 0.005]
+    mask, counts = hip.radius_mark(src, qry, dist, k=k, device=gpu)
+    want_idx, want_counts = _kdtree_union(src, qry, dist, k)
+    assert np.array_equal(counts, want_counts)
+    assert np.array_equal(np.flatnonzero(mask), want_idx)
+    if k < 100:
+        assert counts.max() == k                           # the cap was exercised
+
+
+def test_radius_mark_strict_bound_and_outside_queries(gpu):
+    src = np.array([[0.0, 0, 0], [0.5, 0, 0], [1.0, 0, 0], [0.25, 0, 0]])
+    qry = np.array([[0.0, 0, 0], [100.0, 100, 100], [-3.0, 0, 0]])
+    mask, counts = hip.radius_mark(src, qry, 0.5, k=4, device=gpu)
+    assert list(np.flatnonzero(mask)) == [0, 3]            # 0.5 itself is excluded (strict)
+    assert list(counts) == [2, 0, 0]
+
+
+def test_ball_query_matches_ckdtree(gpu):
+    P = synth.forest(50_000, seed=2)
+    tree = cKDTree(P)
+    for center, r in (([0.1, 0.0, 3.0], 0.5), ([2.0, 2.0, 2.0], 0.05), ([0, 0, 0], 100.0)):
+        got = hip.ball_query(P, center, r, device=gpu)
+        want = np.sort(tree.query_ball_point(center, r))
+        assert np.array_equal(got, want)
+
+
+def test_wrappers(gpu):
+    P = synth.forest(20_000, seed=3)
+    stem = P[(P[:, 2] > 1.0) & (P[:, 2] < 1.3) & (np.hypot(P[:, 0], P[:, 1]) < 0.4)]
+    sphere, nbrs, center, radius = find_neighbors_in_ball(stem, P, [])
+    want = np.sort(cKDTree(P).query_ball_point(center, radius))
+    assert np.array_equal(nbrs, want) and 0.01 <= radius <= 1.5
+    pcd, counts, uniq = get_neighbors_kdtree(P, query_pts=stem, dist=0.3)
+    want_idx, _ = _kdtree_union(P, stem, 0.3, 500)
+    assert np.array_equal(uniq, want_idx) and len(pcd.points) == len(uniq)
+    assert get_neighbors_kdtree(P, query_pts=np.array([[99.0, 99, 99]]), dist=0.1) == (None,) * 3
+    idx = get_neighbors_in_tree(stem, P, 0.2)
+    t_sub = cKDTree(stem)
+    pairs = cKDTree(P).query_ball_tree(t_sub, r=0.2)
+    assert np.array_equal(idx, np.array([i for i, p in enumerate(pairs) if p]))
