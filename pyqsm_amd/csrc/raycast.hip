@@ -26,7 +26,9 @@
 //         | (det < 0 & U <= 0 & V <= 0 & W <= 0 & Tn < 0)
 //   t = Tn / det, u = U / det, v = V / det   (IEEE division)
 //   closest hit: strictly smaller t wins, so ties go to the lowest triangle id.
-#include "common.hpp"
+#include "grid.hpp"
+
+#include <cmath>
 
 namespace pyqsm {
 
@@ -356,6 +358,231 @@ __global__ __launch_bounds__(256) void k_cast_parallel(const TriRec* __restrict_
   }
 }
 
+// ---- parallel rays with conservative cluster culling ---------------------------------
+// Still no hierarchy: the triangles are sorted once per call by the cell of their
+// centroid on the plane normal to the common direction (the counting sort of
+// grid.hip), cut into clusters of kCluster consecutive triangles, and every cluster
+// carries the bounding rectangle of its members on that plane. A wave computes the
+// rectangle of its own rays' origins on the same plane once, and walks the cluster
+// list with one scalar rectangle test per cluster; only overlapping clusters run the
+// Moller-Trumbore code of k_cast_parallel, unchanged. Rectangles are grown by a margin
+// four orders of magnitude above fp32 rounding, so no test that could hit is skipped
+// and t, u, v and the primitive id stay bit-identical to the brute-force sweep (the
+// closest-hit rule compares (t, original triangle id), so the processing order does
+// not matter).
+
+static constexpr int kCluster = 16;
+
+struct Basis {
+  double ux, uy, uz, vx, vy, vz;
+};
+
+// per triangle: centroid on the plane (for sorting) and bounding rectangle
+__global__ __launch_bounds__(256) void k_tri_uv(const TriRec* __restrict__ tri, int64_t T, Basis b,
+                                                double* __restrict__ cen /*[T][3]*/,
+                                                float4* __restrict__ rect /*[T]*/) {
+  int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+  if (i >= T) return;
+  const Tri t = load_tri(tri, int(i));
+  const double px[3] = {double(t.v0x), double(t.v0x) + double(t.e1x), double(t.v0x) + double(t.e2x)};
+  const double py[3] = {double(t.v0y), double(t.v0y) + double(t.e1y), double(t.v0y) + double(t.e2y)};
+  const double pz[3] = {double(t.v0z), double(t.v0z) + double(t.e1z), double(t.v0z) + double(t.e2z)};
+  double u0 = 1e300, u1 = -1e300, v0 = 1e300, v1 = -1e300, uc = 0.0, vc = 0.0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double u = px[k] * b.ux + py[k] * b.uy + pz[k] * b.uz;
+    const double v = px[k] * b.vx + py[k] * b.vy + pz[k] * b.vz;
+    u0 = u < u0 ? u : u0;
+    u1 = u > u1 ? u : u1;
+    v0 = v < v0 ? v : v0;
+    v1 = v > v1 ? v : v1;
+    uc += u;
+    vc += v;
+  }
+  cen[3 * i] = uc / 3.0;
+  cen[3 * i + 1] = vc / 3.0;
+  cen[3 * i + 2] = 0.0;
+  rect[i] = make_float4(__double2float_rd(u0), __double2float_ru(u1), __double2float_rd(v0),
+                        __double2float_ru(v1));
+}
+
+// sorted front records, original ids, and one grown rectangle per cluster
+__global__ __launch_bounds__(256) void k_clusters(const TriRec* __restrict__ tri, int T,
+                                                  const float* __restrict__ rays,
+                                                  const int32_t* __restrict__ order,
+                                                  const float4* __restrict__ rect, float margin,
+                                                  DirRec* __restrict__ srec,
+                                                  int32_t* __restrict__ sid,
+                                                  float4* __restrict__ crect) {
+  const int cl = blockIdx.x * 256 + threadIdx.x;
+  const int nclus = (T + kCluster - 1) / kCluster;
+  if (cl >= nclus) return;
+  RayPair r;
+  r.ox = r.oy = r.oz = splat(0.f);
+  r.dx = splat(rays[3]);
+  r.dy = splat(rays[4]);
+  r.dz = splat(rays[5]);
+  float u0 = __builtin_inff(), u1 = -__builtin_inff(), v0 = __builtin_inff(), v1 = -__builtin_inff();
+  for (int s = cl * kCluster; s < (cl + 1) * kCluster && s < T; ++s) {
+    const int o = order[s];
+    const Tri t = load_tri(tri, o);
+    f2 px, py, pz, det, tvx, tvy, tvz, U;
+    mt_front(r, t, px, py, pz, det, tvx, tvy, tvz, U);
+    srec[s] = DirRec{t.v0x, t.v0y, t.v0z, px[0], py[0], pz[0], det[0], 0.f};
+    sid[s] = o;
+    const float4 q = rect[o];
+    u0 = fminf(u0, q.x);
+    u1 = fmaxf(u1, q.y);
+    v0 = fminf(v0, q.z);
+    v1 = fmaxf(v1, q.w);
+  }
+  crect[cl] = make_float4(u0 - margin, u1 + margin, v0 - margin, v1 + margin);
+}
+
+static constexpr int kSuper = 32;  // clusters per super-cluster (second level of rectangles)
+
+__global__ __launch_bounds__(256) void k_super_rects(int nclus, const float4* __restrict__ crect,
+                                                     float4* __restrict__ srect) {
+  const int sc = blockIdx.x * 256 + threadIdx.x;
+  const int nsup = (nclus + kSuper - 1) / kSuper;
+  if (sc >= nsup) return;
+  float u0 = __builtin_inff(), u1 = -__builtin_inff(), v0 = __builtin_inff(), v1 = -__builtin_inff();
+  for (int cl = sc * kSuper; cl < (sc + 1) * kSuper && cl < nclus; ++cl) {
+    const float4 q = crect[cl];
+    u0 = fminf(u0, q.x);
+    u1 = fmaxf(u1, q.y);
+    v0 = fminf(v0, q.z);
+    v1 = fmaxf(v1, q.w);
+  }
+  srect[sc] = make_float4(u0, u1, v0, v1);
+}
+
+__device__ __forceinline__ float wave_min_f(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_max_f(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+template <int NP>
+__global__ __launch_bounds__(256) void k_cast_parallel_culled(
+    const TriRec* __restrict__ tri, const DirRec* __restrict__ srec,
+    const int32_t* __restrict__ sid, const float4* __restrict__ crect,
+    const float4* __restrict__ srect, int T, Basis b,
+    const float* __restrict__ rays, int64_t R, float* __restrict__ t_hit,
+    uint32_t* __restrict__ prim_id, float* __restrict__ uv) {
+  constexpr int RPL = 2 * NP;
+  // a wave owns 64*RPL CONSECUTIVE rays, so that its rectangle on the plane is small
+  const int64_t block_base =
+      int64_t(blockIdx.x) * (256 * RPL) + int64_t(threadIdx.x >> 6) * (64 * RPL) + (threadIdx.x & 63);
+  f2 ox[NP], oy[NP], oz[NP];
+  float best_t[RPL];
+  uint32_t best_p[RPL];
+  double umin = 1e300, umax = -1e300, vmin = 1e300, vmax = -1e300;
+#pragma unroll
+  for (int k = 0; k < RPL; ++k) {
+    int64_t r = block_base + int64_t(k) * 64;
+    float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+    if (r < R) {
+      const float* p = rays + 6 * r;
+      o0 = p[0]; o1 = p[1]; o2 = p[2];
+      const double u = double(o0) * b.ux + double(o1) * b.uy + double(o2) * b.uz;
+      const double v = double(o0) * b.vx + double(o1) * b.vy + double(o2) * b.vz;
+      umin = u < umin ? u : umin;
+      umax = u > umax ? u : umax;
+      vmin = v < vmin ? v : vmin;
+      vmax = v > vmax ? v : vmax;
+    }
+    ox[k >> 1][k & 1] = o0; oy[k >> 1][k & 1] = o1; oz[k >> 1][k & 1] = o2;
+    best_t[k] = __builtin_inff();
+    best_p[k] = PYQSM_MISS_PRIM;
+  }
+  // rectangle of this wave's ray origins on the plane (wave-uniform)
+  const float ru0 = wave_min_f(__double2float_rd(umin)), ru1 = wave_max_f(__double2float_ru(umax));
+  const float rv0 = wave_min_f(__double2float_rd(vmin)), rv1 = wave_max_f(__double2float_ru(vmax));
+  const float d0 = rays[3], d1 = rays[4], d2 = rays[5];
+
+  auto sweep = [&](const Front f, const int s) {
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      const f2 tvx = ox[q] - splat(f.v0x), tvy = oy[q] - splat(f.v0y), tvz = oz[q] - splat(f.v0z);
+      const f2 U = fma2(tvx, splat(f.px), fma2(tvy, splat(f.py), tvz * splat(f.pz)));
+      const f2 det = splat(f.det);
+      const f2 key = alive_key(det, U);
+      bool alive = u_alive(key[0], f.det) || u_alive(key[1], f.det);
+      if (__builtin_amdgcn_ballot_w64(alive) != 0) {
+        const uint32_t id = uint32_t(sid[s]);
+        const Tri t = load_tri(tri, int(id));
+        RayPair r;
+        r.dx = splat(d0); r.dy = splat(d1); r.dz = splat(d2);
+        f2 V, Tn;
+        mt_back(r, t, tvx, tvy, tvz, V, Tn);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          if (is_hit(f.det, U[h], V[h], Tn[h])) {
+            float tt = Tn[h] / f.det;
+            // same winner as the in-order sweep: smallest t, then smallest triangle id
+            if (tt < best_t[2 * q + h] || (tt == best_t[2 * q + h] && id < best_p[2 * q + h])) {
+              best_t[2 * q + h] = tt;
+              best_p[2 * q + h] = id;
+            }
+          }
+        }
+      }
+    }
+  };
+  const int nclus = (T + kCluster - 1) / kCluster;
+  const int nsup = (nclus + kSuper - 1) / kSuper;
+  // the rectangles are uniform across the wave; make that explicit so that the tests
+  // below are scalar compares of SGPR values
+  const float su0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ru0)));
+  const float su1 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ru1)));
+  const float sv0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, rv0)));
+  const float sv1 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, rv1)));
+  float4 nxt = srect[0];
+  for (int sc = 0; sc < nsup; ++sc) {
+    const float4 sr = nxt;  // next super rectangle is in flight while this one is tested
+    nxt = srect[sc + 1 < nsup ? sc + 1 : sc];
+    if (su1 < sr.x || su0 > sr.y || sv1 < sr.z || sv0 > sr.w) continue;
+    const int c1 = (sc + 1) * kSuper < nclus ? (sc + 1) * kSuper : nclus;
+    for (int cl = sc * kSuper; cl < c1; ++cl) {
+      const float4 cr = crect[cl];  // wave-uniform address
+      if (su1 < cr.x || su0 > cr.y || sv1 < cr.z || sv0 > cr.w) continue;
+      const int s1 = (cl + 1) * kCluster < T ? (cl + 1) * kCluster : T;
+      for (int s = cl * kCluster; s < s1; ++s) sweep(load_front(srec, s), s);
+    }
+  }
+
+#pragma unroll
+  for (int k = 0; k < RPL; ++k) {
+    int64_t r = block_base + int64_t(k) * 64;
+    if (r >= R) continue;
+    t_hit[r] = best_t[k];
+    prim_id[r] = best_p[k];
+    if (uv) {
+      float u = 0.f, v = 0.f;
+      if (best_p[k] != PYQSM_MISS_PRIM) {
+        const Tri t = load_tri(tri, int(best_p[k]));
+        RayPair one;
+        const int q = k >> 1, h = k & 1;
+        one.ox = splat(ox[q][h]); one.oy = splat(oy[q][h]); one.oz = splat(oz[q][h]);
+        one.dx = splat(d0); one.dy = splat(d1); one.dz = splat(d2);
+        f2 px, py, pz, det, tvx, tvy, tvz, U, V, Tn;
+        mt_front(one, t, px, py, pz, det, tvx, tvy, tvz, U);
+        mt_back(one, t, tvx, tvy, tvz, V, Tn);
+        u = U[0] / det[0];
+        v = V[0] / det[0];
+      }
+      uv[2 * r] = u;
+      uv[2 * r + 1] = v;
+    }
+  }
+}
+
 // Crossing counts and (optionally) hit records: one ray per lane, all triangles.
 // mode 0: counts only. mode 1: write records at offsets[r] + running index.
 template <int MODE>
@@ -466,6 +693,84 @@ static int launch_cast(Ctx* c, const TriRec* tri, int64_t T, const float* rays, 
   const int64_t waves_needed = int64_t(c->cu_count) * 8;
   const int np = R >= waves_needed * 64 * 8 ? 4 : (R >= waves_needed * 64 * 4 ? 2 : 1);
   const dim3 grid(ceil_div(R, 256 * 2 * np)), block(256);
+  const char* cull_env = getenv("PYQSM_RAY_CULL");
+  const bool cull = !(cull_env && cull_env[0] == '0');
+  if (!varied && cull && T >= 4 * kCluster) {
+    // ---- sort triangles on the plane normal to d, build clusters, culled sweep ------
+    float hd[3];
+    PQ_HIP(hipMemcpyAsync(hd, rays + 3, 12, hipMemcpyDeviceToHost, c->stream));
+    PQ_HIP(hipStreamSynchronize(c->stream));
+    const double dn = std::sqrt(double(hd[0]) * hd[0] + double(hd[1]) * hd[1] + double(hd[2]) * hd[2]);
+    if (dn > 0.0 && std::isfinite(dn)) {
+      const double d[3] = {hd[0] / dn, hd[1] / dn, hd[2] / dn};
+      // first plane axis: the direction in which consecutive ray origins advance (ray
+      // grids are stored row by row, so rows become thin rectangles); any vector
+      // normal to d otherwise
+      double u[3] = {0, 0, 0}, un = 0.0;
+      if (R >= 2) {
+        float ho[12];
+        PQ_HIP(hipMemcpyAsync(ho, rays, 48, hipMemcpyDeviceToHost, c->stream));
+        PQ_HIP(hipStreamSynchronize(c->stream));
+        const double s0[3] = {double(ho[6]) - ho[0], double(ho[7]) - ho[1], double(ho[8]) - ho[2]};
+        const double along = s0[0] * d[0] + s0[1] * d[1] + s0[2] * d[2];
+        for (int a = 0; a < 3; ++a) u[a] = s0[a] - along * d[a];
+        un = std::sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+      }
+      if (!(un > 1e-12 * (1.0 + std::fabs(double(hd[0])) + std::fabs(double(hd[1]))))) {
+        double h[3] = {0, 0, 0};
+        const double ax = std::fabs(d[0]), ay = std::fabs(d[1]), az = std::fabs(d[2]);
+        h[ax <= ay && ax <= az ? 0 : (ay <= az ? 1 : 2)] = 1.0;
+        u[0] = d[1] * h[2] - d[2] * h[1];
+        u[1] = d[2] * h[0] - d[0] * h[2];
+        u[2] = d[0] * h[1] - d[1] * h[0];
+        un = std::sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+      }
+      for (double& q : u) q /= un;
+      const double v[3] = {d[1] * u[2] - d[2] * u[1], d[2] * u[0] - d[0] * u[2],
+                           d[0] * u[1] - d[1] * u[0]};
+      const Basis bs{u[0], u[1], u[2], v[0], v[1], v[2]};
+      double* cen = nullptr;
+      float4 *rect = nullptr, *crect = nullptr, *srect = nullptr;
+      DirRec* srec = nullptr;
+      int32_t* sid = nullptr;
+      const int nclus = int((T + kCluster - 1) / kCluster);
+      PQ_TRY(c->arena.get(size_t(T) * 3, &cen));
+      PQ_TRY(c->arena.get(size_t(T), &rect));
+      PQ_TRY(c->arena.get(size_t(nclus), &crect));
+      const int nsup = (nclus + kSuper - 1) / kSuper;
+      PQ_TRY(c->arena.get(size_t(nsup), &srect));
+      PQ_TRY(c->arena.get(size_t(T), &srec));
+      PQ_TRY(c->arena.get(size_t(T), &sid));
+      hipLaunchKernelGGL(k_tri_uv, dim3(ceil_div(T, 256)), dim3(256), 0, c->stream, tri, T, bs, cen,
+                         rect);
+      PQ_HIP(hipGetLastError());
+      double mn[3], mx[3];
+      PQ_TRY(cloud_bbox(c, cen, T, mn, mx));
+      double ext = std::max(mx[0] - mn[0], mx[1] - mn[1]);
+      if (!(ext > 0)) ext = 1.0;
+      double box[6] = {mn[0], mn[1], mn[2], mx[0], mx[1], mx[2]};
+      DevGrid g;
+      PQ_TRY(build_grid(c, cen, T, ext / 1024.0, int64_t(1) << 22, &g, box));
+      const float margin = float(1e-4 * ext + 1e-30);
+      hipLaunchKernelGGL(k_clusters, dim3(ceil_div(nclus, 256)), dim3(256), 0, c->stream, tri, int(T),
+                         rays, g.order, rect, margin, srec, sid, crect);
+      hipLaunchKernelGGL(k_super_rects, dim3(ceil_div(nsup, 256)), dim3(256), 0, c->stream, nclus,
+                         crect, srect);
+      PQ_HIP(hipGetLastError());
+      ProfScope ps(c, "cast_rays_culled");
+      if (np == 4)
+        hipLaunchKernelGGL(k_cast_parallel_culled<4>, grid, block, 0, c->stream, tri, srec, sid, crect,
+                           srect, int(T), bs, rays, R, t_hit, prim, uv);
+      else if (np == 2)
+        hipLaunchKernelGGL(k_cast_parallel_culled<2>, grid, block, 0, c->stream, tri, srec, sid, crect,
+                           srect, int(T), bs, rays, R, t_hit, prim, uv);
+      else
+        hipLaunchKernelGGL(k_cast_parallel_culled<1>, grid, block, 0, c->stream, tri, srec, sid, crect,
+                           srect, int(T), bs, rays, R, t_hit, prim, uv);
+      PQ_HIP(hipGetLastError());
+      return 0;
+    }
+  }
   if (!varied) {
     DirRec* rec = nullptr;
     PQ_TRY(c->arena.get(size_t(T), &rec));
@@ -547,6 +852,7 @@ int pyqsm_cast_rays_dev(const float* tri12_dev, int64_t T, const float* rays_dev
   Ctx* c = ctx_for(device);
   if (!c) return PYQSM_ENODEV;
   std::lock_guard<std::mutex> lk(c->mu);
+  c->arena.reset();  // scratch of the previous call (per-direction records, sort buffers)
   return launch_cast(c, reinterpret_cast<const TriRec*>(tri12_dev), T, rays_dev, R, t_hit_dev,
                      prim_id_dev, uv_dev);
 }

@@ -43,6 +43,20 @@ def test_sun_rays_all_kernel_widths(gpu):
         _check(verts, tris, rays, gpu)
 
 
+def test_parallel_rays_brute_force_and_culled_agree(gpu, monkeypatch):
+    """The same batch through the cluster-culled sweep (default for one-direction
+    batches) and through the plain brute-force parallel kernel (PYQSM_RAY_CULL=0):
+    both must equal the oracle bit for bit."""
+    verts, tris = synth.canopy_mesh(20_000, seed=4, side=0.15)
+    rays = synth.sun_rays(verts, 300_000, elevation_deg=35.0, azimuth_deg=20.0)
+    t0, p0, uv0 = oracle.cast_rays(verts, tris, rays)
+    for flag in ("1", "0"):
+        monkeypatch.setenv("PYQSM_RAY_CULL", flag)
+        t, p, uv = hip.cast_rays(verts, tris, rays, device=gpu)
+        assert np.array_equal(t, t0) and np.array_equal(p, p0) and np.array_equal(uv, uv0), flag
+    assert np.isfinite(t0).mean() > 0.2
+
+
 def test_unit_triangle_known_answers(gpu):
     verts = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], dtype=np.float32)
     tris = np.array([[0, 1, 2]], dtype=np.int32)

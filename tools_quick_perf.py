@@ -38,4 +38,4 @@ if what in ("all", "rays"):
         hip.prof_reset()
         t = time.time(); hip.cast_rays_dev(mesh, d_rays.ptr, R, d_t.ptr, d_p.ptr); hip.sync(); dt = time.time() - t
         th = d_t.download((R,), np.float32)
-        print(f"rays R={R} T={T} wall {dt*1e3:.1f} ms -> {R*T/dt/1e6:.3e} Mray-tri/s hits={np.isfinite(th).mean():.3f}", hip.prof_get("cast_rays"), flush=True)
+        print(f"rays R={R} T={T} wall {dt*1e3:.1f} ms -> {R*T/dt/1e6:.3e} Mray-tri/s hits={np.isfinite(th).mean():.3f}", hip.prof_get("cast_rays"), hip.prof_get("cast_rays_culled"), flush=True)
