@@ -123,6 +123,17 @@ __device__ __forceinline__ bool u_alive(float key, float det) {
   return __builtin_fabsf(key) <= __builtin_fabsf(det);
 }
 
+// Same decision with the sign of det supplied by the caller (for the parallel-ray
+// kernels det is a per-triangle scalar, and its sign is taken from the integer bits
+// on the scalar unit: det > 0 <=> bits > 0, det < 0 <=> bits < 0 and bits != -0).
+__device__ __forceinline__ bool is_hit_signed(bool det_pos, bool det_neg, float det, float U,
+                                              float V, float Tn) {
+  float W = det - (U + V);
+  bool pos = det_pos && U >= 0.f && V >= 0.f && W >= 0.f && Tn > 0.f;
+  bool neg = det_neg && U <= 0.f && V <= 0.f && W <= 0.f && Tn < 0.f;
+  return pos || neg;
+}
+
 __device__ __forceinline__ bool is_hit(float det, float U, float V, float Tn) {
   float W = det - (U + V);
   bool pos = det > 0.f && U >= 0.f && V >= 0.f && W >= 0.f && Tn > 0.f;
@@ -296,6 +307,8 @@ __global__ __launch_bounds__(256) void k_cast_parallel(const TriRec* __restrict_
   const float d0 = rays[3], d1 = rays[4], d2 = rays[5];  // the common direction
 
   auto sweep = [&](const Front f, const int j) {
+    const int dbits = __builtin_bit_cast(int, f.det);
+    const bool det_pos = dbits > 0, det_neg = dbits < 0 && dbits != int(0x80000000u);
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
       const f2 tvx = ox[q] - splat(f.v0x), tvy = oy[q] - splat(f.v0y), tvz = oz[q] - splat(f.v0z);
@@ -311,7 +324,7 @@ __global__ __launch_bounds__(256) void k_cast_parallel(const TriRec* __restrict_
         mt_back(r, t, tvx, tvy, tvz, V, Tn);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          if (is_hit(f.det, U[h], V[h], Tn[h])) {
+          if (is_hit_signed(det_pos, det_neg, f.det, U[h], V[h], Tn[h])) {
             float tt = Tn[h] / f.det;
             if (tt < best_t[2 * q + h]) {
               best_t[2 * q + h] = tt;
@@ -507,6 +520,8 @@ __global__ __launch_bounds__(256) void k_cast_parallel_culled(
   const float d0 = rays[3], d1 = rays[4], d2 = rays[5];
 
   auto sweep = [&](const Front f, const int s) {
+    const int dbits = __builtin_bit_cast(int, f.det);
+    const bool det_pos = dbits > 0, det_neg = dbits < 0 && dbits != int(0x80000000u);
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
       const f2 tvx = ox[q] - splat(f.v0x), tvy = oy[q] - splat(f.v0y), tvz = oz[q] - splat(f.v0z);
@@ -523,7 +538,7 @@ __global__ __launch_bounds__(256) void k_cast_parallel_culled(
         mt_back(r, t, tvx, tvy, tvz, V, Tn);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          if (is_hit(f.det, U[h], V[h], Tn[h])) {
+          if (is_hit_signed(det_pos, det_neg, f.det, U[h], V[h], Tn[h])) {
             float tt = Tn[h] / f.det;
             // same winner as the in-order sweep: smallest t, then smallest triangle id
             if (tt < best_t[2 * q + h] || (tt == best_t[2 * q + h] && id < best_p[2 * q + h])) {
@@ -691,8 +706,14 @@ static int launch_cast(Ctx* c, const TriRec* tri, int64_t T, const float* rays, 
   // Rays per lane: 8 when there are enough rays to fill the chip that way,
   // fewer for small batches so that more waves exist.
   const int64_t waves_needed = int64_t(c->cu_count) * 8;
-  const int np = R >= waves_needed * 64 * 8 ? 4 : (R >= waves_needed * 64 * 4 ? 2 : 1);
-  const dim3 grid(ceil_div(R, 256 * 2 * np)), block(256);
+  int np = R >= waves_needed * 64 * 8 ? 4 : (R >= waves_needed * 64 * 4 ? 2 : 1);
+  // (12 rays per lane, np = 6, measured 4 % slower than 8 on the 10 M x 500 k sweep)
+  if (const char* e = getenv("PYQSM_RAY_NP")) {  // tuning knob
+    const int v = atoi(e);
+    if (v == 1 || v == 2 || v == 4 || v == 6) np = v;
+  }
+  const dim3 block(256);
+  auto grid_for = [&](int npv) { return dim3(ceil_div(R, 256 * 2 * npv)); };
   const char* cull_env = getenv("PYQSM_RAY_CULL");
   const bool cull = !(cull_env && cull_env[0] == '0');
   if (!varied && cull && T >= 4 * kCluster) {
@@ -758,14 +779,15 @@ static int launch_cast(Ctx* c, const TriRec* tri, int64_t T, const float* rays, 
                          crect, srect);
       PQ_HIP(hipGetLastError());
       ProfScope ps(c, "cast_rays_culled");
+      if (np == 6) np = 4;  // the culled kernel is not VALU bound: smaller waves' rectangles win
       if (np == 4)
-        hipLaunchKernelGGL(k_cast_parallel_culled<4>, grid, block, 0, c->stream, tri, srec, sid, crect,
+        hipLaunchKernelGGL(k_cast_parallel_culled<4>, grid_for(4), block, 0, c->stream, tri, srec, sid, crect,
                            srect, int(T), bs, rays, R, t_hit, prim, uv);
       else if (np == 2)
-        hipLaunchKernelGGL(k_cast_parallel_culled<2>, grid, block, 0, c->stream, tri, srec, sid, crect,
+        hipLaunchKernelGGL(k_cast_parallel_culled<2>, grid_for(2), block, 0, c->stream, tri, srec, sid, crect,
                            srect, int(T), bs, rays, R, t_hit, prim, uv);
       else
-        hipLaunchKernelGGL(k_cast_parallel_culled<1>, grid, block, 0, c->stream, tri, srec, sid, crect,
+        hipLaunchKernelGGL(k_cast_parallel_culled<1>, grid_for(1), block, 0, c->stream, tri, srec, sid, crect,
                            srect, int(T), bs, rays, R, t_hit, prim, uv);
       PQ_HIP(hipGetLastError());
       return 0;
@@ -777,27 +799,31 @@ static int launch_cast(Ctx* c, const TriRec* tri, int64_t T, const float* rays, 
     hipLaunchKernelGGL(k_dir_records, dim3(ceil_div(T, 256)), dim3(256), 0, c->stream, tri, T, rays,
                        rec);
     ProfScope ps(c, "cast_rays");
-    if (np == 4)
-      hipLaunchKernelGGL(k_cast_parallel<4>, grid, block, 0, c->stream, tri, rec, int(T), rays, R,
+    if (np == 6)
+      hipLaunchKernelGGL(k_cast_parallel<6>, grid_for(6), block, 0, c->stream, tri, rec, int(T), rays, R,
+                         t_hit, prim, uv);
+    else if (np == 4)
+      hipLaunchKernelGGL(k_cast_parallel<4>, grid_for(4), block, 0, c->stream, tri, rec, int(T), rays, R,
                          t_hit, prim, uv);
     else if (np == 2)
-      hipLaunchKernelGGL(k_cast_parallel<2>, grid, block, 0, c->stream, tri, rec, int(T), rays, R,
+      hipLaunchKernelGGL(k_cast_parallel<2>, grid_for(2), block, 0, c->stream, tri, rec, int(T), rays, R,
                          t_hit, prim, uv);
     else
-      hipLaunchKernelGGL(k_cast_parallel<1>, grid, block, 0, c->stream, tri, rec, int(T), rays, R,
+      hipLaunchKernelGGL(k_cast_parallel<1>, grid_for(1), block, 0, c->stream, tri, rec, int(T), rays, R,
                          t_hit, prim, uv);
     PQ_HIP(hipGetLastError());
     return 0;
   }
   ProfScope ps(c, "cast_rays");
+  if (np == 6) np = 4;
   if (np == 4)
-    hipLaunchKernelGGL(k_cast_rays<4>, grid, block, 0, c->stream, tri, int(T), rays, R, t_hit, prim,
+    hipLaunchKernelGGL(k_cast_rays<4>, grid_for(4), block, 0, c->stream, tri, int(T), rays, R, t_hit, prim,
                        uv);
   else if (np == 2)
-    hipLaunchKernelGGL(k_cast_rays<2>, grid, block, 0, c->stream, tri, int(T), rays, R, t_hit, prim,
+    hipLaunchKernelGGL(k_cast_rays<2>, grid_for(2), block, 0, c->stream, tri, int(T), rays, R, t_hit, prim,
                        uv);
   else
-    hipLaunchKernelGGL(k_cast_rays<1>, grid, block, 0, c->stream, tri, int(T), rays, R, t_hit, prim,
+    hipLaunchKernelGGL(k_cast_rays<1>, grid_for(1), block, 0, c->stream, tri, int(T), rays, R, t_hit, prim,
                        uv);
   PQ_HIP(hipGetLastError());
   return 0;
