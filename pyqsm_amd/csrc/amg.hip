@@ -37,6 +37,8 @@ struct AmgLevel {
 };
 
 struct AmgHierarchy {
+  int sweeps = 1;        // l1-Jacobi sweeps before and after the coarse correction
+  double alpha = 1.0;    // scaling of the piecewise-constant coarse correction
   std::vector<AmgLevel> lv;
   double* dense_inv = nullptr;  // [nc, nc] on the device
   int nc = 0;
@@ -224,13 +226,13 @@ __global__ __launch_bounds__(256) void k_restrict(int n, const int32_t* __restri
 }
 
 __global__ __launch_bounds__(256) void k_prolong_add(int n, const int32_t* __restrict__ agg,
-                                                     const double* __restrict__ xc,
+                                                     const double* __restrict__ xc, double alpha,
                                                      double* __restrict__ x) {
   int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const int a = agg[i];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) x[3 * i + k] += xc[3 * a + k];
+  for (int k = 0; k < 3; ++k) x[3 * i + k] += alpha * xc[3 * a + k];
 }
 
 // x += dinv .* r
@@ -328,6 +330,11 @@ int amg_build(Ctx* c, const DevCsr& Lm, int n, double cw, const double* wh, cons
               AmgHierarchy** out) {
   *out = nullptr;
   AmgHierarchy* H = new AmgHierarchy();
+  if (const char* e = getenv("PYQSM_AMG_SWEEPS")) H->sweeps = std::max(1, std::min(8, atoi(e)));
+  if (const char* e = getenv("PYQSM_AMG_ALPHA")) {
+    const double v = atof(e);
+    if (v > 0.0 && v < 4.0) H->alpha = v;
+  }
   auto bail = [&](int rc) {
     delete H;
     return rc;
@@ -475,6 +482,11 @@ int amg_vcycle(Ctx* c, AmgHierarchy* H, const double* b, double* x) {
       break;
     }
     hipLaunchKernelGGL(k_smooth0, g, blk, 0, c->stream, L.n, L.dinv, bl, xl);
+    for (int sw = 1; sw < H->sweeps && l < nl - 1; ++sw) {
+      hipLaunchKernelGGL(k_residual, g, blk, 0, c->stream, L.n, L.A.indptr, L.A.indices, L.A.vals, bl,
+                         xl, L.r);
+      hipLaunchKernelGGL(k_correct, g, blk, 0, c->stream, L.n, L.dinv, L.r, xl);
+    }
     if (l == nl - 1) {  // coarsest without a dense solve: a few more sweeps
       for (int s = 0; s < 4; ++s) {
         hipLaunchKernelGGL(k_residual, g, blk, 0, c->stream, L.n, L.A.indptr, L.A.indices, L.A.vals,
@@ -496,10 +508,12 @@ int amg_vcycle(Ctx* c, AmgHierarchy* H, const double* b, double* x) {
     const double* bl = l == 0 ? b : L.b;
     double* xl = l == 0 ? x : L.x;
     const dim3 g(ceil_div(L.n, 256));
-    hipLaunchKernelGGL(k_prolong_add, g, blk, 0, c->stream, L.n, L.agg, C.x, xl);
-    hipLaunchKernelGGL(k_residual, g, blk, 0, c->stream, L.n, L.A.indptr, L.A.indices, L.A.vals, bl,
-                       xl, L.r);
-    hipLaunchKernelGGL(k_correct, g, blk, 0, c->stream, L.n, L.dinv, L.r, xl);
+    hipLaunchKernelGGL(k_prolong_add, g, blk, 0, c->stream, L.n, L.agg, C.x, H->alpha, xl);
+    for (int sw = 0; sw < H->sweeps; ++sw) {
+      hipLaunchKernelGGL(k_residual, g, blk, 0, c->stream, L.n, L.A.indptr, L.A.indices, L.A.vals, bl,
+                         xl, L.r);
+      hipLaunchKernelGGL(k_correct, g, blk, 0, c->stream, L.n, L.dinv, L.r, xl);
+    }
   }
   PQ_HIP(hipGetLastError());
   return 0;
