@@ -273,6 +273,110 @@ int build_grid(Ctx* c, const double* xyz, int64_t n, double min_cell, int64_t ma
   return 0;
 }
 
+
+// ---- pyramid coarsening: a grid with cells `factor` times larger, without atomics ----
+// Coarse cell C gathers the factor^3 fine cells of its block; their point runs are
+// concatenated in (z, y, x) order, so a point's new position follows from its old one:
+// coarse_start[C] + offset_of_its_fine_cell_in_C + (old position - fine_start[cell]).
+
+struct Pyr {
+  int fnx, fny, fnz, cnx, cny, cnz, factor;
+};
+
+__device__ __forceinline__ int coarse_of(const Pyr& P, int f) {
+  const int fx = f % P.fnx, fy = (f / P.fnx) % P.fny, fz = f / (P.fnx * P.fny);
+  // interior fine index i (1..n-2) holds coordinate i-1; borders stay borders
+  auto m = [&](int i, int fn, int cn) {
+    if (i <= 0) return 0;
+    if (i >= fn - 1) return cn - 1;
+    return (i - 1) / P.factor + 1;
+  };
+  const int cx = m(fx, P.fnx, P.cnx), cy = m(fy, P.fny, P.cny), cz = m(fz, P.fnz, P.cnz);
+  return (cz * P.cny + cy) * P.cnx + cx;
+}
+
+__global__ __launch_bounds__(256) void k_pyr_counts(Pyr P, const int32_t* __restrict__ fstart,
+                                                    int32_t* __restrict__ ccount,
+                                                    int32_t* __restrict__ foff) {
+  const int C = blockIdx.x * 256 + threadIdx.x;
+  if (C >= P.cnx * P.cny * P.cnz) return;
+  const int cx = C % P.cnx, cy = (C / P.cnx) % P.cny, cz = C / (P.cnx * P.cny);
+  int run = 0;
+  if (cx >= 1 && cy >= 1 && cz >= 1 && cx <= P.cnx - 2 && cy <= P.cny - 2 && cz <= P.cnz - 2) {
+    const int x0 = (cx - 1) * P.factor + 1, y0 = (cy - 1) * P.factor + 1, z0 = (cz - 1) * P.factor + 1;
+    for (int z = z0; z < z0 + P.factor && z <= P.fnz - 2; ++z)
+      for (int y = y0; y < y0 + P.factor && y <= P.fny - 2; ++y)
+        for (int x = x0; x < x0 + P.factor && x <= P.fnx - 2; ++x) {
+          const int f = (z * P.fny + y) * P.fnx + x;
+          foff[f] = run;
+          run += fstart[f + 1] - fstart[f];
+        }
+  }
+  ccount[C] = run;
+}
+
+__global__ __launch_bounds__(256) void k_pyr_scatter(int n, Pyr P, const int32_t* __restrict__ fstart,
+                                                     const int32_t* __restrict__ cstart,
+                                                     const int32_t* __restrict__ foff,
+                                                     const int32_t* __restrict__ f_cell_of,
+                                                     const int32_t* __restrict__ f_order,
+                                                     const double* __restrict__ fx,
+                                                     const double* __restrict__ fy,
+                                                     const double* __restrict__ fz,
+                                                     int32_t* __restrict__ order,
+                                                     int32_t* __restrict__ cell_of,
+                                                     double* __restrict__ sx,
+                                                     double* __restrict__ sy,
+                                                     double* __restrict__ sz) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= n) return;
+  const int f = f_cell_of[p];
+  const int C = coarse_of(P, f);
+  const int q = cstart[C] + foff[f] + (p - fstart[f]);
+  order[q] = f_order[p];
+  cell_of[q] = C;
+  sx[q] = fx[p];
+  sy[q] = fy[p];
+  sz[q] = fz[p];
+}
+
+int coarsen_grid(Ctx* c, const DevGrid& fine, int64_t n, int factor, DevGrid* g) {
+  if (factor < 2) return fail(PYQSM_EINVAL, "coarsen_grid: factor must be >= 2");
+  Pyr P;
+  P.factor = factor;
+  P.fnx = fine.nx;
+  P.fny = fine.ny;
+  P.fnz = fine.nz;
+  P.cnx = (fine.nx - 2 + factor - 1) / factor + 2;
+  P.cny = (fine.ny - 2 + factor - 1) / factor + 2;
+  P.cnz = (fine.nz - 2 + factor - 1) / factor + 2;
+  *g = fine;
+  g->nx = P.cnx;
+  g->ny = P.cny;
+  g->nz = P.cnz;
+  g->cell = fine.cell * factor;
+  g->inv_cell = 1.0 / g->cell;
+  g->ncell = int64_t(P.cnx) * P.cny * P.cnz;
+  int32_t* foff = nullptr;
+  PQ_TRY(c->arena.get(size_t(fine.ncell) + 1, &foff));
+  PQ_TRY(c->arena.get(size_t(g->ncell) + 1, &g->start));
+  PQ_TRY(c->arena.get(size_t(n), &g->order));
+  PQ_TRY(c->arena.get(size_t(n), &g->cell_of));
+  PQ_TRY(c->arena.get(size_t(n), &g->sx));
+  PQ_TRY(c->arena.get(size_t(n), &g->sy));
+  PQ_TRY(c->arena.get(size_t(n), &g->sz));
+  PQ_HIP(hipMemsetAsync(g->start + g->ncell, 0, 4, c->stream));
+  hipLaunchKernelGGL(k_pyr_counts, dim3(ceil_div(g->ncell, 256)), dim3(256), 0, c->stream, P,
+                     fine.start, g->start, foff);
+  PQ_HIP(hipGetLastError());
+  PQ_TRY(exclusive_scan_i32(c, g->start, g->ncell + 1));
+  hipLaunchKernelGGL(k_pyr_scatter, dim3(ceil_div(n, 256)), dim3(256), 0, c->stream, int(n), P,
+                     fine.start, g->start, foff, fine.cell_of, fine.order, fine.sx, fine.sy, fine.sz,
+                     g->order, g->cell_of, g->sx, g->sy, g->sz);
+  PQ_HIP(hipGetLastError());
+  return 0;
+}
+
 int count_occupied(Ctx* c, const DevGrid& g, int64_t* occupied) {
   int32_t* d = nullptr;
   PQ_TRY(c->arena.get(1, &d));

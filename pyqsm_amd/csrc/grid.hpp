@@ -41,6 +41,10 @@ int cloud_bbox(Ctx* c, const double* xyz, int64_t n, double mn[3], double mx[3])
 int probe_occupancy(Ctx* c, const double* xyz, int64_t n, const double box[6], double cell,
                     double* cell_used, double* per_cell);
 
+// A grid with cells `factor` times larger over the same points, derived from `fine`
+// by block sums and a deterministic scatter (no atomics, no second pass over xyz).
+int coarsen_grid(Ctx* c, const DevGrid& fine, int64_t n, int factor, DevGrid* coarse);
+
 // Number of occupied cells (reads back one int; synchronises).
 int count_occupied(Ctx* c, const DevGrid& g, int64_t* occupied);
 

@@ -347,7 +347,11 @@ int knn_device(Ctx* c, const double* xyz, int64_t n, int32_t k, int32_t exclude_
     ProfScope ps(c, "knn_bin");
     list = (level & 1) ? fail_b : fail_a;
     n_query = nf;
-    PQ_TRY(build_grid(c, xyz, n, g.cell * 4.0, max_cells, &g));
+    {
+      DevGrid coarse;
+      PQ_TRY(coarsen_grid(c, g, n, 4, &coarse));
+      g = coarse;
+    }
     if (!pos_of) PQ_TRY(c->arena.get(size_t(n), &pos_of));
     hipLaunchKernelGGL(k_invert_order, dim3(ceil_div(n, 256)), dim3(256), 0, c->stream, N, g.order,
                        pos_of);
