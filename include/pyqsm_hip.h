@@ -172,10 +172,14 @@ int pyqsm_ransac_count(const double* pts, int64_t n, const double* models, int64
  * gradient over 3 right-hand sides that never forms L'L.
  *   L as CSR (indptr i32 [n+1], indices i32 [nnz], vals f64 [nnz]);
  *   wl, wh, f64 [n]; pts f64 [n,3] (also the start vector); out f64 [n,3]
- *   stops when |r|/|b| <= rtol for every coordinate, after max_it iterations, or
- *   when the residual has stopped improving (attainable accuracy reached); in the
- *   last two cases returns PYQSM_ENOCONV with the best iterate in `out` and its
- *   residuals in `resid`.
+ *   uniform wl (what extract_skeleton produces): flexible CG preconditioned by
+ *   B^-2, B = c L + W_H; stops when the preconditioned residual |B^-2 r| / |x|,
+ *   an estimate of the relative error of x (B^-2 A has its spectrum in [1/2, 1]
+ *   for uniform W_H), is <= rtol for every coordinate; non-uniform wl: Jacobi-CG,
+ *   stops when |r|/|b| <= rtol. Also stops after max_it sparse passes or when
+ *   the estimate has stopped improving (attainable accuracy); in those two cases
+ *   returns PYQSM_ENOCONV with the best iterate in `out`. `resid` always receives
+ *   the true relative residuals |r|/|b| of the returned iterate.
  */
 int pyqsm_lbc_solve(const int32_t* indptr, const int32_t* indices, const double* vals,
                     int64_t n, const double* wl, const double* wh, const double* pts,

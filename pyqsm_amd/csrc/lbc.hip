@@ -19,10 +19,10 @@
 namespace pyqsm {
 
 static constexpr int kBurst = 24;  // CG iterations per graph replay / residual check
-static constexpr double kInnerRtolDefault = 1e-6;  // B-solves inside the preconditioner
+static constexpr double kInnerRtolDefault = 1e-2;  // B-solves inside the preconditioner (flexible CG outside)
 static constexpr int kInnerMaxIt = 200000;
-static constexpr int kOuterMaxIt = 200;
-static constexpr int kOuterStall = 6;
+static constexpr int kOuterMaxIt = 600;
+static constexpr int kOuterStall = 12;
 static constexpr int kAmgMaxIt = 400;   // multigrid-preconditioned CG iterations per B-solve
 static constexpr int kStallIters = 1500;
 // CG residuals are not monotone, so stagnation only counts once the solve is
@@ -686,15 +686,44 @@ int lbc_solve_device(Ctx* c, const DevCsr& L, int64_t n, const double* wl, doubl
     }
     return worst;
   };
-  double best = rel(rr, resid);
+  // Convergence is judged on z = B^-2 r: B^-2 A has its spectrum in [1/2, 1] for uniform
+  // W_H (a modest interval otherwise), so |z| / |x| estimates the relative ERROR of x, which
+  // is what the caller's 1e-5 position tolerance is about. The true residual |r| / |b| is
+  // tracked as well (and reported), but with cond(A) up to 1e10 it is neither monotone
+  // under CG nor a usable measure of the error.
+  rel(rr, resid);
+  double cur_res[3] = {resid[0], resid[1], resid[2]};
+  double best = HUGE_VAL;
   double best_res[3] = {resid[0], resid[1], resid[2]};
   PQ_HIP(hipMemcpyAsync(x_best, x, size_t(n) * 24, hipMemcpyDeviceToDevice, c->stream));
   int outer = 0, best_outer = 0;
-  bool done = best <= rtol;
+  bool done = std::max(resid[0], std::max(resid[1], resid[2])) <= rtol;
+  const bool trace = getenv("PYQSM_LBC_TRACE") != nullptr;
+  // after every preconditioner application: error estimate of the current x
+  auto judge = [&]() -> int {
+    double zz[3], xx[3];
+    PQ_TRY(dot3_host(c, N, z, z, d_tmp, zz));
+    PQ_TRY(dot3_host(c, N, x, x, d_tmp, xx));
+    double est = 0.0;
+    for (int k = 0; k < 3; ++k) est = std::max(est, xx[k] > 0 ? std::sqrt(zz[k] / xx[k]) : 0.0);
+    if (trace)
+      fprintf(stderr, "lbc outer %d inner %d resid %.3e est %.3e\n", outer, total_inner,
+              std::max(cur_res[0], std::max(cur_res[1], cur_res[2])), est);
+    if (!std::isfinite(est)) return 1;
+    if (est < best) {
+      best = est;
+      best_outer = outer;
+      for (int k = 0; k < 3; ++k) best_res[k] = cur_res[k];
+      PQ_HIP(hipMemcpyAsync(x_best, x, size_t(n) * 24, hipMemcpyDeviceToDevice, c->stream));
+    }
+    if (est <= rtol) done = true;
+    return 0;
+  };
   if (!done) {
     PQ_TRY(precond(r, z));
     PQ_HIP(hipMemcpyAsync(dir, z, size_t(n) * 24, hipMemcpyDeviceToDevice, c->stream));
     PQ_TRY(dot3_host(c, N, r, z, d_tmp, rz));
+    if (judge() != 0) return fail(PYQSM_EHIP, "contraction solve: non-finite preconditioned residual");
   }
   while (!done && outer < kOuterMaxIt && total_inner < max_it) {
     ProfScope ps(c, "lbc_outer_iter");
@@ -710,21 +739,14 @@ int lbc_solve_device(Ctx* c, const DevCsr& L, int64_t n, const double* wl, doubl
     hipLaunchKernelGGL(k_axpy3, grid, block, 0, c->stream, N, nalpha, q, r);
     PQ_TRY(dot3_host(c, N, r, r, d_tmp, rr));
     ++outer;
-    const double worst = rel(rr, resid);
+    const double worst = rel(rr, cur_res);
     if (!std::isfinite(worst)) break;
-    if (worst < best) {
-      best = worst;
-      best_outer = outer;
-      for (int k = 0; k < 3; ++k) best_res[k] = resid[k];
-      PQ_HIP(hipMemcpyAsync(x_best, x, size_t(n) * 24, hipMemcpyDeviceToDevice, c->stream));
-    }
-    if (worst <= rtol) {
-      done = true;
-      break;
-    }
-    if (outer - best_outer >= kOuterStall) break;  // attainable accuracy reached
     PQ_HIP(hipMemcpyAsync(z_old, z, size_t(n) * 24, hipMemcpyDeviceToDevice, c->stream));
     PQ_TRY(precond(r, z));
+    const int jr = judge();
+    if (jr < 0) return jr;
+    if (jr > 0 || done) break;
+    if (outer - best_outer >= kOuterStall) break;  // attainable accuracy reached
     // flexible (Polak-Ribiere) beta: the inner solves are not exact
     double rz_new[3], rzo[3];
     PQ_TRY(dot3_host(c, N, r, z, d_tmp, rz_new));
@@ -743,8 +765,8 @@ int lbc_solve_device(Ctx* c, const DevCsr& L, int64_t n, const double* wl, doubl
   for (int k = 0; k < 3; ++k) resid[k] = best_res[k];
   if (!done)
     return fail(PYQSM_ENOCONV,
-                "contraction solve stopped after %d outer / %d inner iterations; best residual "
-                "%.3e", outer, total_inner, best);
+                "contraction solve stopped after %d outer / %d inner iterations; best error "
+                "estimate %.3e", outer, total_inner, best);
   return 0;
 }
 

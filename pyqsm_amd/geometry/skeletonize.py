@@ -30,7 +30,7 @@ except ImportError:  # flat import (pyqsm_amd/ on sys.path)
     from pyqsm_amd.geometry.cloud import PointCloud, as_points
 
 _SK = config["skeletonize"]
-SOLVER_RTOL = 1e-12      # relative residual of the normal equations at which CG stops
+SOLVER_RTOL = 1e-10      # relative error estimate |B^-2 r| / |x| at which the solve stops
 SOLVER_MAX_IT = 5_000_000   # cap on the total number of inner CG iterations
 
 
@@ -71,8 +71,8 @@ def least_squares_sparse(pts, L, laplacian_weighting, positional_weighting, trun
                                         rtol=rtol, max_it=max_it, device=device)
     if not ok:
         # the best iterate is returned; near cond(A) * 1e-16 the residual cannot go lower
-        log.warning(f"contraction solve stopped after {iters} CG iterations at relative "
-                    f"residual {resid.max():.3e} (requested {rtol:.1e})")
+        log.warning(f"contraction solve stopped after {iters} CG iterations before the error "
+                    f"estimate reached {rtol:.1e} (relative residual {resid.max():.3e})")
     else:
         log.info(f"contraction solve: {iters} CG iterations, residual {resid.max():.3e}")
     if np.isnan(x).all():

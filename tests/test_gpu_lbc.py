@@ -25,8 +25,8 @@ def _load(path):
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "lbc_*.npz"))))
 def test_solve_matches_spsolve_fixture(gpu, path):
     g, L = _load(path)
-    x, iters, resid, ok = hip.lbc_solve(L, g["wl"], g["wh"], g["points"], rtol=1e-12,
-                                        max_it=20000, device=gpu)
+    x, iters, resid, ok = hip.lbc_solve(L, g["wl"], g["wh"], g["points"], rtol=1e-10,
+                                        max_it=200000, device=gpu)
     assert ok, (iters, resid)
     sol = g["solution"]
     scale = np.abs(sol).max()
