@@ -40,13 +40,17 @@ def main():
                                             attraction_factor=args.attraction)
     wall = time.perf_counter() - t0
     prof = {k: hip.prof_get(k) for k in ("lap_knn", "lap_fans", "lap_assemble", "lbc_inner_iter",
+                                         "lbc_amg_iter", "lbc_amg_build",
                                          "lbc_outer_iter", "lbc_cg_iter", "clamp")}
     out = {"config": f"{args.points}-point forest, {len(steps)} contraction steps, "
                      f"init_contraction={args.contraction}",
            "wall_s": wall, "s_per_iteration": wall / max(len(steps), 1),
            "laplacian_ms": sum(prof[k][0] for k in ("lap_knn", "lap_fans", "lap_assemble")),
-           "solve_inner_iterations": prof["lbc_inner_iter"][1],
-           "solve_inner_ms": prof["lbc_inner_iter"][0],
+           "solve_multigrid_cg_iterations": prof["lbc_amg_iter"][1],
+           "solve_multigrid_cg_ms": prof["lbc_amg_iter"][0],
+           "solve_multigrid_setup_ms": prof["lbc_amg_build"][0],
+           "solve_jacobi_cg_iterations": prof["lbc_inner_iter"][1],
+           "solve_jacobi_cg_ms": prof["lbc_inner_iter"][0],
            "solve_outer_iterations": prof["lbc_outer_iter"][1],
            "solve_outer_ms_incl_inner": prof["lbc_outer_iter"][0],
            "mean_shift_m": float(np.linalg.norm(total, axis=1).mean())}

@@ -1,19 +1,30 @@
 // amg.hip — aggregation multigrid preconditioner for B = c*L + W_H, the inner
 // operator of the contraction solve (lbc.hip, DESIGN.md "Contraction solve").
 //
-// cond(B) reaches 1e6 on contracted clouds, so Jacobi-PCG needs 10^4-10^5
-// iterations per inner solve; one V-cycle of this hierarchy as the CG
-// preconditioner brings that to a few dozen.
+// B is a symmetric M-matrix (the flipped tufted Laplacian has no positive
+// off-diagonal entry), cond(B) ~ 1e3..1e6. Jacobi-PCG needs 200-700 iterations
+// for six digits; one V-cycle of this hierarchy as the CG preconditioner needs
+// 35-50 (measured on 200 k-point forests over four contractions).
 //
-//   aggregation   points that fall in the same cell of a uniform grid (edge
-//                 chosen for ~8 points per aggregate; the edge doubles per level)
-//   prolongation  piecewise constant; restriction = its transpose
-//   coarse matrix Galerkin P'BP, accumulated into a per-row open-addressing table
-//                 with atomics, then compacted to CSR with sorted columns
-//   smoother      l1-Jacobi (x += (b - Bx)_i / sum_j |B_ij|): convergent for any
-//                 SPD matrix, no eigenvalue estimate needed
+//   strength      j is a strong neighbour of i  <=>  |a_ij| >= theta * sqrt(a_ii a_jj)
+//   aggregation   a maximal independent set of the SQUARED strength graph (MIS-2,
+//                 hashed priorities, a handful of rounds) gives the roots; every
+//                 other point joins the root it reaches in one or two strong steps.
+//                 Points without any strong neighbour are left out of the coarse
+//                 levels (their rows are diagonally dominant: the smoother alone
+//                 handles them), which keeps the hierarchy shrinking to a few dozen
+//                 unknowns even on clouds made of many disconnected pieces.
+//   prolongation  piecewise constant; restriction = its transpose, applied as a
+//                 gather over each aggregate's sorted member list (no atomics)
+//   coarse matrix Galerkin P'BP, one lane per coarse row accumulating into a
+//                 sorted LDS list in a fixed order: deterministic, symmetric
+//   smoother      l1-Jacobi (x += (b - Bx)_i / sum_j |B_ij|), one sweep before and
+//                 one after the coarse correction, fused with the residual and the
+//                 prolongation: three launches per level and cycle
 //   coarsest      <= kCoarseMax unknowns: dense inverse computed on the host once
 //
+// Geometric (cell) aggregation, the first version of this file, ignored the
+// connectivity and needed ~100 cycles per solve; strength-based aggregates need 35-50.
 // Everything works on three right-hand sides at a time ([n,3] row-major).
 #include "grid.hpp"
 #include "sparse.hpp"
@@ -22,23 +33,27 @@
 
 namespace pyqsm {
 
-static constexpr int kCoarseMax = 96;     // dense solve at or below this size
-static constexpr int kTableCap = 128;     // distinct coarse neighbours per row (hash slots)
+static constexpr int kCoarseMax = 96;   // dense solve at or below this size
+static constexpr int kRowCap = 64;      // distinct coarse neighbours one coarse row may have
 static constexpr int kMaxLevels = 24;
-static constexpr int kEmpty = -1;
+static constexpr double kTheta = 0.08;  // strength-of-connection threshold
+static constexpr int kTailSweeps = 8;   // l1-Jacobi sweeps on a coarsest level too big for a dense solve
+
+enum : int32_t { kUndecided = 0, kIn = 1, kOut = 2 };
+static constexpr unsigned long long kInf = ~0ull;
 
 struct AmgLevel {
   int n = 0;
   DevCsr A{nullptr, nullptr, nullptr};
-  double* dinv = nullptr;   // 1 / sum_j |A_ij|
-  int32_t* agg = nullptr;   // fine dof -> coarse dof (absent on the coarsest level)
-  int32_t* cell = nullptr;  // [n][3] integer cell coordinates at the NEXT level's edge
-  double *r = nullptr, *x = nullptr, *b = nullptr;  // [n,3] work vectors (b, x unused on level 0)
+  double* diag = nullptr;     // a_ii
+  double* dinv = nullptr;     // 1 / sum_j |a_ij|
+  int32_t* agg = nullptr;     // fine dof -> coarse dof, -1 = not represented below (absent on the last level)
+  int32_t* mptr = nullptr;    // coarse dof -> its fine members (CSR over `members`, ascending)
+  int32_t* members = nullptr;
+  double *r = nullptr, *xa = nullptr, *xb = nullptr, *b = nullptr;  // [n,3]; b, xb unused on level 0
 };
 
 struct AmgHierarchy {
-  int sweeps = 1;        // l1-Jacobi sweeps before and after the coarse correction
-  double alpha = 1.0;    // scaling of the piecewise-constant coarse correction
   std::vector<AmgLevel> lv;
   double* dense_inv = nullptr;  // [nc, nc] on the device
   int nc = 0;
@@ -46,13 +61,19 @@ struct AmgHierarchy {
 
 // ---- level construction kernels ------------------------------------------------
 
-__global__ __launch_bounds__(256) void k_l1_diag(int n, const int32_t* __restrict__ indptr,
+__global__ __launch_bounds__(256) void k_diag_l1(int n, const int32_t* __restrict__ indptr,
+                                                 const int32_t* __restrict__ indices,
                                                  const double* __restrict__ vals,
+                                                 double* __restrict__ diag,
                                                  double* __restrict__ dinv) {
   int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  double s = 0.0;
-  for (int j = indptr[i]; j < indptr[i + 1]; ++j) s += fabs(vals[j]);
+  double s = 0.0, d = 0.0;
+  for (int j = indptr[i]; j < indptr[i + 1]; ++j) {
+    s += fabs(vals[j]);
+    if (indices[j] == i) d = vals[j];
+  }
+  diag[i] = d;
   dinv[i] = s > 0.0 ? 1.0 / s : 1.0;
 }
 
@@ -68,138 +89,324 @@ __global__ __launch_bounds__(256) void k_make_b(int n, const int32_t* __restrict
     bvals[j] = cw * lvals[j] + (indices[j] == i ? wh[i] : 0.0);
 }
 
-__global__ __launch_bounds__(256) void k_point_cells(int n, const double* __restrict__ xyz,
-                                                     double mx, double my, double mz, double inv,
-                                                     int32_t* __restrict__ cell) {
-  int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  cell[3 * i] = int(floor((xyz[3 * i] - mx) * inv));
-  cell[3 * i + 1] = int(floor((xyz[3 * i + 1] - my) * inv));
-  cell[3 * i + 2] = int(floor((xyz[3 * i + 2] - mz) * inv));
+__device__ __forceinline__ bool strong(int i, int j, double v, const double* __restrict__ diag) {
+  return j != i && v * v >= (kTheta * kTheta) * diag[i] * diag[j];
 }
 
-__device__ __forceinline__ int64_t cell_key(const int32_t* cell, int i, int nx, int ny, int nz) {
-  int cx = cell[3 * i], cy = cell[3 * i + 1], cz = cell[3 * i + 2];
-  cx = cx < 0 ? 0 : (cx >= nx ? nx - 1 : cx);
-  cy = cy < 0 ? 0 : (cy >= ny ? ny - 1 : cy);
-  cz = cz < 0 ? 0 : (cz >= nz ? nz - 1 : cz);
-  return (int64_t(cz) * ny + cy) * nx + cx;
+__device__ __forceinline__ unsigned long long priority(int i) {
+  unsigned h = unsigned(i) * 0x9E3779B1u;
+  h ^= h >> 16;
+  h *= 0x85EBCA6Bu;
+  h ^= h >> 13;
+  h *= 0xC2B2AE35u;
+  h ^= h >> 16;
+  return ((unsigned long long)(h >> 1) << 32) | (unsigned long long)(unsigned(i) + 1u);
 }
 
-__global__ __launch_bounds__(256) void k_flag_cells(int n, const int32_t* __restrict__ cell, int nx,
-                                                    int ny, int nz, int32_t* __restrict__ flags) {
-  int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n) flags[cell_key(cell, i, nx, ny, nz)] = 1;
-}
-
-// agg[i] = compact id of i's cell; the coarse dof inherits the cell coordinates halved
-__global__ __launch_bounds__(256) void k_assign_agg(int n, const int32_t* __restrict__ cell, int nx,
-                                                    int ny, int nz,
-                                                    const int32_t* __restrict__ ids,
-                                                    int32_t* __restrict__ agg,
-                                                    int32_t* __restrict__ coarse_cell) {
-  int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const int a = ids[cell_key(cell, i, nx, ny, nz)];
-  agg[i] = a;
-  coarse_cell[3 * a] = cell[3 * i] >> 1;      // every member writes the same values
-  coarse_cell[3 * a + 1] = cell[3 * i + 1] >> 1;
-  coarse_cell[3 * a + 2] = cell[3 * i + 2] >> 1;
-}
-
-__global__ __launch_bounds__(256) void k_halve_cells(int n, int32_t* __restrict__ cell) {
-  int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  cell[3 * i] >>= 1;
-  cell[3 * i + 1] >>= 1;
-  cell[3 * i + 2] >>= 1;
-}
-
-// Galerkin product into per-row hash tables: table[I][slot] += A_ij for J = agg[j]
-__global__ __launch_bounds__(256) void k_galerkin(int n, const int32_t* __restrict__ indptr,
+__global__ __launch_bounds__(256) void k_mis_init(int n, const int32_t* __restrict__ indptr,
                                                   const int32_t* __restrict__ indices,
                                                   const double* __restrict__ vals,
-                                                  const int32_t* __restrict__ agg,
-                                                  int32_t* __restrict__ tkeys,
-                                                  double* __restrict__ tvals,
-                                                  int32_t* __restrict__ overflow) {
+                                                  const double* __restrict__ diag,
+                                                  int32_t* __restrict__ state,
+                                                  unsigned long long* __restrict__ key) {
   int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  const int I = agg[i];
-  int32_t* keys = tkeys + size_t(I) * kTableCap;
-  double* tv = tvals + size_t(I) * kTableCap;
+  bool any = false;
+  for (int j = indptr[i]; j < indptr[i + 1] && !any; ++j) any = strong(i, indices[j], vals[j], diag);
+  state[i] = any ? kUndecided : kOut;
+  key[i] = any ? priority(i) : 0ull;
+}
+
+// out[i] = max(in[i], in[j] over the strong neighbours j)
+__global__ __launch_bounds__(256) void k_mis_max(int n, const int32_t* __restrict__ indptr,
+                                                 const int32_t* __restrict__ indices,
+                                                 const double* __restrict__ vals,
+                                                 const double* __restrict__ diag,
+                                                 const unsigned long long* __restrict__ in,
+                                                 unsigned long long* __restrict__ out) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  unsigned long long m = in[i];
   for (int j = indptr[i]; j < indptr[i + 1]; ++j) {
-    const int J = agg[indices[j]];
-    unsigned slot = (unsigned(J) * 2654435761u) % kTableCap;
-    int probes = 0;
-    for (;;) {
-      const int prev = atomicCAS(&keys[slot], kEmpty, J);
-      if (prev == kEmpty || prev == J) {
-        atomicAdd(&tv[slot], vals[j]);
-        break;
-      }
-      slot = (slot + 1) % kTableCap;
-      if (++probes >= kTableCap) {
-        *overflow = 1;
-        break;
-      }
+    const int col = indices[j];
+    if (strong(i, col, vals[j], diag)) {
+      const unsigned long long v = in[col];
+      m = v > m ? v : m;
     }
+  }
+  out[i] = m;
+}
+
+// An undecided point whose key is the largest within two strong steps becomes a root;
+// one that sees a root within two steps is out. `left` counts the still undecided.
+__global__ __launch_bounds__(256) void k_mis_update(int n, const unsigned long long* __restrict__ t2,
+                                                    int32_t* __restrict__ state,
+                                                    unsigned long long* __restrict__ key,
+                                                    int32_t* __restrict__ left) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  bool still = false;
+  if (i < n && state[i] == kUndecided) {
+    const unsigned long long m = t2[i];
+    if (m == key[i]) {
+      state[i] = kIn;
+      key[i] = kInf;
+    } else if (m == kInf) {
+      state[i] = kOut;
+      key[i] = 0ull;
+    } else {
+      still = true;
+    }
+  }
+  const unsigned long long b = __ballot(still);
+  if (b != 0 && (threadIdx.x & 63) == 0) atomicAdd(left, __popcll(b));
+}
+
+__global__ __launch_bounds__(256) void k_root_flags(int n, const int32_t* __restrict__ state,
+                                                    int32_t* __restrict__ flags) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) flags[i] = state[i] == kIn;
+}
+
+// pass 1: roots take their id, direct strong neighbours of a root join it (largest id wins)
+__global__ __launch_bounds__(256) void k_agg1(int n, const int32_t* __restrict__ indptr,
+                                              const int32_t* __restrict__ indices,
+                                              const double* __restrict__ vals,
+                                              const double* __restrict__ diag,
+                                              const int32_t* __restrict__ state,
+                                              const int32_t* __restrict__ ids,
+                                              int32_t* __restrict__ agg1) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  int a = -1;
+  if (state[i] == kIn) {
+    a = ids[i];
+  } else {
+    for (int j = indptr[i]; j < indptr[i + 1]; ++j) {
+      const int col = indices[j];
+      if (state[col] == kIn && strong(i, col, vals[j], diag)) a = max(a, ids[col]);
+    }
+  }
+  agg1[i] = a;
+}
+
+// pass 2: the rest joins through a strong neighbour that was placed in pass 1
+__global__ __launch_bounds__(256) void k_agg2(int n, const int32_t* __restrict__ indptr,
+                                              const int32_t* __restrict__ indices,
+                                              const double* __restrict__ vals,
+                                              const double* __restrict__ diag,
+                                              const int32_t* __restrict__ agg1,
+                                              int32_t* __restrict__ agg,
+                                              int32_t* __restrict__ counts) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  int a = agg1[i];
+  if (a < 0) {
+    for (int j = indptr[i]; j < indptr[i + 1]; ++j) {
+      const int col = indices[j];
+      if (strong(i, col, vals[j], diag)) a = max(a, agg1[col]);
+    }
+  }
+  agg[i] = a;
+  if (a >= 0) atomicAdd(&counts[a], 1);
+}
+
+__global__ __launch_bounds__(256) void k_fill_members(int n, const int32_t* __restrict__ agg,
+                                                      const int32_t* __restrict__ mptr,
+                                                      int32_t* __restrict__ cursor,
+                                                      int32_t* __restrict__ members) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int a = agg[i];
+  if (a >= 0) members[mptr[a] + atomicAdd(&cursor[a], 1)] = i;
+}
+
+__global__ __launch_bounds__(256) void k_sort_members(int nc, const int32_t* __restrict__ mptr,
+                                                      int32_t* __restrict__ members) {
+  int a = blockIdx.x * 256 + threadIdx.x;
+  if (a >= nc) return;
+  const int b = mptr[a], e = mptr[a + 1];
+  for (int p = b + 1; p < e; ++p) {
+    const int v = members[p];
+    int q = p;
+    while (q > b && members[q - 1] > v) {
+      members[q] = members[q - 1];
+      --q;
+    }
+    members[q] = v;
   }
 }
 
-__global__ __launch_bounds__(256) void k_table_counts(int nc, const int32_t* __restrict__ tkeys,
-                                                      int32_t* __restrict__ counts) {
-  int I = blockIdx.x * 256 + threadIdx.x;
+// Galerkin row I = sum over members i of I, entries (i, j): (agg[j], a_ij). One lane per
+// coarse row; the row is kept as a column-sorted list in LDS (slot-major, so the 64
+// lanes of the block touch 64 consecutive words), members and entries are visited in
+// a fixed order: the sums are reproducible and the result is exactly symmetric when A is.
+__global__ __launch_bounds__(64) void k_galerkin_rows(int nc, const int32_t* __restrict__ mptr,
+                                                      const int32_t* __restrict__ members,
+                                                      const int32_t* __restrict__ indptr,
+                                                      const int32_t* __restrict__ indices,
+                                                      const double* __restrict__ vals,
+                                                      const int32_t* __restrict__ agg,
+                                                      int32_t* __restrict__ counts,
+                                                      int32_t* __restrict__ tkeys,
+                                                      double* __restrict__ tvals,
+                                                      int32_t* __restrict__ overflow) {
+  __shared__ int32_t sk[kRowCap][64];
+  __shared__ double sv[kRowCap][64];
+  const int t = threadIdx.x;
+  const int I = blockIdx.x * 64 + t;
   if (I >= nc) return;
-  int c = 0;
-  for (int s = 0; s < kTableCap; ++s) c += tkeys[size_t(I) * kTableCap + s] != kEmpty;
-  counts[I] = c;
+  int cnt = 0;
+  bool over = false;
+  for (int m = mptr[I]; m < mptr[I + 1]; ++m) {
+    const int i = members[m];
+    for (int e = indptr[i]; e < indptr[i + 1]; ++e) {
+      const int J = agg[indices[e]];
+      if (J < 0) continue;
+      const double v = vals[e];
+      int p = 0;
+      while (p < cnt && sk[p][t] < J) ++p;
+      if (p < cnt && sk[p][t] == J) {
+        sv[p][t] += v;
+      } else if (cnt < kRowCap) {
+        for (int q = cnt; q > p; --q) {
+          sk[q][t] = sk[q - 1][t];
+          sv[q][t] = sv[q - 1][t];
+        }
+        sk[p][t] = J;
+        sv[p][t] = v;
+        ++cnt;
+      } else {
+        over = true;
+      }
+    }
+  }
+  if (over) *overflow = 1;
+  counts[I] = cnt;
+  for (int p = 0; p < cnt; ++p) {
+    tkeys[size_t(I) * kRowCap + p] = sk[p][t];
+    tvals[size_t(I) * kRowCap + p] = sv[p][t];
+  }
 }
 
-__global__ __launch_bounds__(256) void k_table_to_csr(int nc, const int32_t* __restrict__ tkeys,
-                                                      const double* __restrict__ tvals,
-                                                      const int32_t* __restrict__ indptr,
-                                                      int32_t* __restrict__ indices,
-                                                      double* __restrict__ vals) {
+__global__ __launch_bounds__(256) void k_rows_to_csr(int nc, const int32_t* __restrict__ tkeys,
+                                                     const double* __restrict__ tvals,
+                                                     const int32_t* __restrict__ indptr,
+                                                     int32_t* __restrict__ indices,
+                                                     double* __restrict__ vals) {
   int I = blockIdx.x * 256 + threadIdx.x;
   if (I >= nc) return;
-  const int b = indptr[I];
-  int m = 0;
-  for (int s = 0; s < kTableCap; ++s) {
-    const int k = tkeys[size_t(I) * kTableCap + s];
-    if (k == kEmpty) continue;
-    const double v = tvals[size_t(I) * kTableCap + s];
-    int j = m++;
-    while (j > 0 && indices[b + j - 1] > k) {  // insertion sort by column
-      indices[b + j] = indices[b + j - 1];
-      vals[b + j] = vals[b + j - 1];
-      --j;
-    }
-    indices[b + j] = k;
-    vals[b + j] = v;
+  const int b = indptr[I], cnt = indptr[I + 1] - b;
+  for (int p = 0; p < cnt; ++p) {
+    indices[b + p] = tkeys[size_t(I) * kRowCap + p];
+    vals[b + p] = tvals[size_t(I) * kRowCap + p];
   }
 }
 
 // ---- cycle kernels ----------------------------------------------------------------
 
-// x = dinv .* b
-__global__ __launch_bounds__(256) void k_smooth0(int n, const double* __restrict__ dinv,
-                                                 const double* __restrict__ b,
-                                                 double* __restrict__ x) {
+// pre-smoothing from a zero start fused with the residual:
+//   x = Dinv b ;  r = b - A x
+__global__ __launch_bounds__(256) void k_down(int n, const int32_t* __restrict__ indptr,
+                                              const int32_t* __restrict__ indices,
+                                              const double* __restrict__ vals,
+                                              const double* __restrict__ dinv,
+                                              const double* __restrict__ b, double* __restrict__ x,
+                                              double* __restrict__ r) {
   int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+  for (int j = indptr[i]; j < indptr[i + 1]; ++j) {
+    const int col = indices[j];
+    const double v = vals[j] * dinv[col];
+    a0 += v * b[3 * col];
+    a1 += v * b[3 * col + 1];
+    a2 += v * b[3 * col + 2];
+  }
   const double d = dinv[i];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) x[3 * i + k] = d * b[3 * i + k];
+  const double b0 = b[3 * i], b1 = b[3 * i + 1], b2 = b[3 * i + 2];
+  x[3 * i] = d * b0;
+  x[3 * i + 1] = d * b1;
+  x[3 * i + 2] = d * b2;
+  r[3 * i] = b0 - a0;
+  r[3 * i + 1] = b1 - a1;
+  r[3 * i + 2] = b2 - a2;
 }
 
-// r = b - A x
-__global__ __launch_bounds__(256) void k_residual(int n, const int32_t* __restrict__ indptr,
-                                                  const int32_t* __restrict__ indices,
-                                                  const double* __restrict__ vals,
-                                                  const double* __restrict__ b,
-                                                  const double* __restrict__ x,
-                                                  double* __restrict__ r) {
+// rc[a] = sum of r over the members of aggregate a
+__global__ __launch_bounds__(256) void k_restrict(int nc, const int32_t* __restrict__ mptr,
+                                                  const int32_t* __restrict__ members,
+                                                  const double* __restrict__ r,
+                                                  double* __restrict__ rc) {
+  int a = blockIdx.x * 256 + threadIdx.x;
+  if (a >= nc) return;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  for (int m = mptr[a]; m < mptr[a + 1]; ++m) {
+    const int i = members[m];
+    s0 += r[3 * i];
+    s1 += r[3 * i + 1];
+    s2 += r[3 * i + 2];
+  }
+  rc[3 * a] = s0;
+  rc[3 * a + 1] = s1;
+  rc[3 * a + 2] = s2;
+}
+
+// coarse correction fused with the post-smoothing sweep:
+//   y = x + P xc ;  out = y + Dinv (b - A y)
+__global__ __launch_bounds__(256) void k_up(int n, const int32_t* __restrict__ indptr,
+                                            const int32_t* __restrict__ indices,
+                                            const double* __restrict__ vals,
+                                            const double* __restrict__ dinv,
+                                            const int32_t* __restrict__ agg,
+                                            const double* __restrict__ xc,
+                                            const double* __restrict__ b,
+                                            const double* __restrict__ x, double* __restrict__ out,
+                                            double* __restrict__ dot /*may be null*/) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  double d0 = 0.0, d1 = 0.0, d2 = 0.0;
+  if (i < n) {
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+  for (int j = indptr[i]; j < indptr[i + 1]; ++j) {
+    const int col = indices[j];
+    const double v = vals[j];
+    const int ac = agg[col];
+    double y0 = x[3 * col], y1 = x[3 * col + 1], y2 = x[3 * col + 2];
+    if (ac >= 0) {
+      y0 += xc[3 * ac];
+      y1 += xc[3 * ac + 1];
+      y2 += xc[3 * ac + 2];
+    }
+    a0 += v * y0;
+    a1 += v * y1;
+    a2 += v * y2;
+  }
+  const int ai = agg[i];
+  double y0 = x[3 * i], y1 = x[3 * i + 1], y2 = x[3 * i + 2];
+  if (ai >= 0) {
+    y0 += xc[3 * ai];
+    y1 += xc[3 * ai + 1];
+    y2 += xc[3 * ai + 2];
+  }
+  const double d = dinv[i];
+  const double b0 = b[3 * i], b1 = b[3 * i + 1], b2 = b[3 * i + 2];
+  const double o0 = y0 + d * (b0 - a0), o1 = y1 + d * (b1 - a1), o2 = y2 + d * (b2 - a2);
+  out[3 * i] = o0;
+  out[3 * i + 1] = o1;
+  out[3 * i + 2] = o2;
+  d0 = b0 * o0;
+  d1 = b1 * o1;
+  d2 = b2 * o2;
+  }
+  if (dot) reduce3_atomic(d0, d1, d2, dot);
+}
+
+// one l1-Jacobi sweep out = x + Dinv (b - A x)   (coarsest level without a dense inverse)
+__global__ __launch_bounds__(256) void k_sweep(int n, const int32_t* __restrict__ indptr,
+                                               const int32_t* __restrict__ indices,
+                                               const double* __restrict__ vals,
+                                               const double* __restrict__ dinv,
+                                               const double* __restrict__ b,
+                                               const double* __restrict__ x, double* __restrict__ out) {
   int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   double a0 = 0.0, a1 = 0.0, a2 = 0.0;
@@ -210,40 +417,20 @@ __global__ __launch_bounds__(256) void k_residual(int n, const int32_t* __restri
     a1 += v * x[3 * col + 1];
     a2 += v * x[3 * col + 2];
   }
-  r[3 * i] = b[3 * i] - a0;
-  r[3 * i + 1] = b[3 * i + 1] - a1;
-  r[3 * i + 2] = b[3 * i + 2] - a2;
+  const double d = dinv[i];
+  out[3 * i] = x[3 * i] + d * (b[3 * i] - a0);
+  out[3 * i + 1] = x[3 * i + 1] + d * (b[3 * i + 1] - a1);
+  out[3 * i + 2] = x[3 * i + 2] + d * (b[3 * i + 2] - a2);
 }
 
-__global__ __launch_bounds__(256) void k_restrict(int n, const int32_t* __restrict__ agg,
-                                                  const double* __restrict__ r,
-                                                  double* __restrict__ rc) {
-  int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const int a = agg[i];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) atomicAdd(&rc[3 * a + k], r[3 * i + k]);
-}
-
-__global__ __launch_bounds__(256) void k_prolong_add(int n, const int32_t* __restrict__ agg,
-                                                     const double* __restrict__ xc, double alpha,
-                                                     double* __restrict__ x) {
-  int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const int a = agg[i];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) x[3 * i + k] += alpha * xc[3 * a + k];
-}
-
-// x += dinv .* r
-__global__ __launch_bounds__(256) void k_correct(int n, const double* __restrict__ dinv,
-                                                 const double* __restrict__ r,
-                                                 double* __restrict__ x) {
+// x = dinv .* b
+__global__ __launch_bounds__(256) void k_scale(int n, const double* __restrict__ dinv,
+                                               const double* __restrict__ b, double* __restrict__ x) {
   int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const double d = dinv[i];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) x[3 * i + k] += d * r[3 * i + k];
+  for (int k = 0; k < 3; ++k) x[3 * i + k] = d * b[3 * i + k];
 }
 
 // x = Ainv * b on the coarsest level (nc <= kCoarseMax), one block
@@ -263,10 +450,11 @@ __global__ __launch_bounds__(128) void k_dense_solve(int nc, const double* __res
 
 // ---- host side ------------------------------------------------------------------------
 
-static int alloc_vectors(Ctx* c, AmgLevel& L, bool need_bx) {
+static int alloc_vectors(Ctx* c, AmgLevel& L, bool coarse) {
   PQ_TRY(c->arena.get(size_t(L.n) * 3, &L.r));
-  if (need_bx) {
-    PQ_TRY(c->arena.get(size_t(L.n) * 3, &L.x));
+  PQ_TRY(c->arena.get(size_t(L.n) * 3, &L.xa));
+  if (coarse) {
+    PQ_TRY(c->arena.get(size_t(L.n) * 3, &L.xb));
     PQ_TRY(c->arena.get(size_t(L.n) * 3, &L.b));
   }
   return 0;
@@ -288,11 +476,6 @@ static int coarse_inverse(Ctx* c, const AmgLevel& L, double** d_inv) {
   std::vector<double> A(size_t(n) * n, 0.0), G(size_t(n) * n, 0.0), inv(size_t(n) * n, 0.0);
   for (int i = 0; i < n; ++i)
     for (int j = ip[size_t(i)]; j < ip[size_t(i) + 1]; ++j) A[size_t(i) * n + ix[size_t(j)]] += va[size_t(j)];
-  for (int i = 0; i < n; ++i)  // symmetrise the atomics' rounding noise
-    for (int j = 0; j < i; ++j) {
-      const double m = 0.5 * (A[size_t(i) * n + j] + A[size_t(j) * n + i]);
-      A[size_t(i) * n + j] = A[size_t(j) * n + i] = m;
-    }
   // Cholesky A = G G'
   for (int j = 0; j < n; ++j) {
     double d = A[size_t(j) * n + j];
@@ -326,15 +509,64 @@ static int coarse_inverse(Ctx* c, const AmgLevel& L, double** d_inv) {
   return 0;
 }
 
-int amg_build(Ctx* c, const DevCsr& Lm, int n, double cw, const double* wh, const double* xyz,
-              AmgHierarchy** out) {
+// Aggregates of level F (strength graph -> MIS-2 roots -> two joining passes -> member
+// lists). Returns the number of aggregates in *nc_out (0: nothing to coarsen).
+static int aggregate(Ctx* c, AmgLevel& F, int32_t* d_counter, int* nc_out) {
+  const int n = F.n;
+  const dim3 g(ceil_div(n, 256)), blk(256);
+  int32_t *state, *flags, *agg1;
+  unsigned long long *key, *t1, *t2;
+  PQ_TRY(c->arena.get(size_t(n), &state));
+  PQ_TRY(c->arena.get(size_t(n) + 1, &flags));
+  PQ_TRY(c->arena.get(size_t(n), &agg1));
+  PQ_TRY(c->arena.get(size_t(n), &key));
+  PQ_TRY(c->arena.get(size_t(n), &t1));
+  PQ_TRY(c->arena.get(size_t(n), &t2));
+  hipLaunchKernelGGL(k_mis_init, g, blk, 0, c->stream, n, F.A.indptr, F.A.indices, F.A.vals, F.diag,
+                     state, key);
+  for (int round = 0; round < 64; ++round) {
+    hipLaunchKernelGGL(k_mis_max, g, blk, 0, c->stream, n, F.A.indptr, F.A.indices, F.A.vals, F.diag,
+                       key, t1);
+    hipLaunchKernelGGL(k_mis_max, g, blk, 0, c->stream, n, F.A.indptr, F.A.indices, F.A.vals, F.diag,
+                       t1, t2);
+    PQ_HIP(hipMemsetAsync(d_counter, 0, 4, c->stream));
+    hipLaunchKernelGGL(k_mis_update, g, blk, 0, c->stream, n, t2, state, key, d_counter);
+    int32_t left = 0;
+    PQ_HIP(hipMemcpyAsync(&left, d_counter, 4, hipMemcpyDeviceToHost, c->stream));
+    PQ_HIP(hipStreamSynchronize(c->stream));
+    if (left == 0) break;
+    if (round == 63) return fail(PYQSM_EHIP, "multigrid: independent-set selection did not finish");
+  }
+  PQ_HIP(hipMemsetAsync(flags + n, 0, 4, c->stream));
+  hipLaunchKernelGGL(k_root_flags, g, blk, 0, c->stream, n, state, flags);
+  PQ_TRY(exclusive_scan_i32(c, flags, int64_t(n) + 1));
+  int32_t nc = 0;
+  PQ_HIP(hipMemcpyAsync(&nc, flags + n, 4, hipMemcpyDeviceToHost, c->stream));
+  PQ_HIP(hipStreamSynchronize(c->stream));
+  *nc_out = nc;
+  if (nc <= 0) return 0;
+  int32_t* cursor;
+  PQ_TRY(c->arena.get(size_t(n), &F.agg));
+  PQ_TRY(c->arena.get(size_t(nc) + 1, &F.mptr));
+  PQ_TRY(c->arena.get(size_t(nc), &cursor));
+  PQ_TRY(c->arena.get(size_t(n), &F.members));
+  PQ_HIP(hipMemsetAsync(F.mptr, 0, (size_t(nc) + 1) * 4, c->stream));
+  PQ_HIP(hipMemsetAsync(cursor, 0, size_t(nc) * 4, c->stream));
+  hipLaunchKernelGGL(k_agg1, g, blk, 0, c->stream, n, F.A.indptr, F.A.indices, F.A.vals, F.diag, state,
+                     flags, agg1);
+  hipLaunchKernelGGL(k_agg2, g, blk, 0, c->stream, n, F.A.indptr, F.A.indices, F.A.vals, F.diag, agg1,
+                     F.agg, F.mptr);
+  PQ_TRY(exclusive_scan_i32(c, F.mptr, int64_t(nc) + 1));
+  hipLaunchKernelGGL(k_fill_members, g, blk, 0, c->stream, n, F.agg, F.mptr, cursor, F.members);
+  hipLaunchKernelGGL(k_sort_members, dim3(ceil_div(nc, 256)), blk, 0, c->stream, nc, F.mptr,
+                     F.members);
+  PQ_HIP(hipGetLastError());
+  return 0;
+}
+
+int amg_build(Ctx* c, const DevCsr& Lm, int n, double cw, const double* wh, AmgHierarchy** out) {
   *out = nullptr;
   AmgHierarchy* H = new AmgHierarchy();
-  if (const char* e = getenv("PYQSM_AMG_SWEEPS")) H->sweeps = std::max(1, std::min(8, atoi(e)));
-  if (const char* e = getenv("PYQSM_AMG_ALPHA")) {
-    const double v = atof(e);
-    if (v > 0.0 && v < 4.0) H->alpha = v;
-  }
   auto bail = [&](int rc) {
     delete H;
     return rc;
@@ -359,104 +591,70 @@ int amg_build(Ctx* c, const DevCsr& Lm, int n, double cw, const double* wh, cons
   l0.A.indptr = Lm.indptr;
   l0.A.indices = Lm.indices;
   AMG_TRY(c->arena.get(size_t(nnz0) + 1, &l0.A.vals));
+  AMG_TRY(c->arena.get(size_t(n), &l0.diag));
   AMG_TRY(c->arena.get(size_t(n), &l0.dinv));
   hipLaunchKernelGGL(k_make_b, dim3(ceil_div(n, 256)), dim3(256), 0, c->stream, n, Lm.indptr,
                      Lm.indices, Lm.vals, cw, wh, l0.A.vals);
-  hipLaunchKernelGGL(k_l1_diag, dim3(ceil_div(n, 256)), dim3(256), 0, c->stream, n, l0.A.indptr,
-                     l0.A.vals, l0.dinv);
+  hipLaunchKernelGGL(k_diag_l1, dim3(ceil_div(n, 256)), dim3(256), 0, c->stream, n, l0.A.indptr,
+                     l0.A.indices, l0.A.vals, l0.diag, l0.dinv);
   AMG_TRY(alloc_vectors(c, l0, false));
-  // ---- first aggregation edge: ~8 points per occupied cell ---------------------------
-  double box[6];
-  AMG_TRY(cloud_bbox(c, xyz, n, box, box + 3));
-  double ext = std::max(box[3] - box[0], std::max(box[4] - box[1], box[5] - box[2]));
-  if (!(ext > 0)) ext = 1.0;
-  const double target = 8.0;
-  double c1, per1, c2, per2, dim = 2.0, edge;
-  AMG_TRY(probe_occupancy(c, xyz, n, box, ext / 64.0, &c1, &per1));
-  if (per1 <= target) {
-    edge = c1;
-  } else {
-    AMG_TRY(probe_occupancy(c, xyz, n, box, c1 * 0.5, &c2, &per2));
-    if (c2 < c1 && per2 > 0) dim = std::log2(std::max(per1 / per2, 1.0001)) / std::log2(c1 / c2);
-    dim = std::min(3.0, std::max(1.0, dim));
-    edge = c2 * std::pow(target / per2, 1.0 / dim);
-  }
-  edge = std::max(edge, ext / 2048.0);
-  AMG_TRY(c->arena.get(size_t(n) * 3, &l0.cell));
-  hipLaunchKernelGGL(k_point_cells, dim3(ceil_div(n, 256)), dim3(256), 0, c->stream, n, xyz, box[0],
-                     box[1], box[2], 1.0 / edge, l0.cell);
-  int dims[3];
-  for (int a = 0; a < 3; ++a) dims[a] = int(std::floor((box[3 + a] - box[a]) / edge)) + 1;
   H->lv.push_back(l0);
   // ---- coarsen -------------------------------------------------------------------------
-  int32_t* d_over = nullptr;
-  AMG_TRY(c->arena.get(1, &d_over));
+  int32_t* d_flag = nullptr;
+  AMG_TRY(c->arena.get(2, &d_flag));
   for (int lev = 0; lev < kMaxLevels; ++lev) {
     AmgLevel& F = H->lv.back();
     if (F.n <= kCoarseMax) break;
-    const int64_t ncell = int64_t(dims[0]) * dims[1] * dims[2];
-    if (ncell > (int64_t(1) << 28)) break;
-    int32_t* flags = nullptr;
-    AMG_TRY(c->arena.get(size_t(ncell) + 1, &flags));
-    AMG_HIP(hipMemsetAsync(flags, 0, (size_t(ncell) + 1) * 4, c->stream));
-    const dim3 gf(ceil_div(F.n, 256)), blk(256);
-    hipLaunchKernelGGL(k_flag_cells, gf, blk, 0, c->stream, F.n, F.cell, dims[0], dims[1], dims[2],
-                       flags);
-    AMG_TRY(exclusive_scan_i32(c, flags, ncell + 1));
-    int32_t nc = 0;
-    AMG_HIP(hipMemcpyAsync(&nc, flags + ncell, 4, hipMemcpyDeviceToHost, c->stream));
-    AMG_HIP(hipStreamSynchronize(c->stream));
-    if (nc <= 0 || nc > 0.7 * F.n) {  // cells too fine to coarsen: double their edge and retry
-      if (dims[0] == 1 && dims[1] == 1 && dims[2] == 1) break;
-      hipLaunchKernelGGL(k_halve_cells, gf, blk, 0, c->stream, F.n, F.cell);
-      for (int a = 0; a < 3; ++a) dims[a] = (dims[a] + 1) / 2;
-      continue;
-    }
-    AmgLevel C;
-    C.n = nc;
-    AMG_TRY(c->arena.get(size_t(F.n), &F.agg));
-    AMG_TRY(c->arena.get(size_t(nc) * 3, &C.cell));
-    hipLaunchKernelGGL(k_assign_agg, gf, blk, 0, c->stream, F.n, F.cell, dims[0], dims[1], dims[2],
-                       flags, F.agg, C.cell);
-    // Galerkin product through per-row hash tables
-    int32_t* tkeys = nullptr;
-    double* tvals = nullptr;
-    AMG_TRY(c->arena.get(size_t(nc) * kTableCap, &tkeys));
-    AMG_TRY(c->arena.get(size_t(nc) * kTableCap, &tvals));
-    AMG_HIP(hipMemsetAsync(tkeys, 0xFF, size_t(nc) * kTableCap * 4, c->stream));
-    AMG_HIP(hipMemsetAsync(tvals, 0, size_t(nc) * kTableCap * 8, c->stream));
-    AMG_HIP(hipMemsetAsync(d_over, 0, 4, c->stream));
-    hipLaunchKernelGGL(k_galerkin, gf, blk, 0, c->stream, F.n, F.A.indptr, F.A.indices, F.A.vals,
-                       F.agg, tkeys, tvals, d_over);
-    AMG_TRY(c->arena.get(size_t(nc) + 1, &C.A.indptr));
-    AMG_HIP(hipMemsetAsync(C.A.indptr, 0, (size_t(nc) + 1) * 4, c->stream));
-    const dim3 gc(ceil_div(nc, 256));
-    hipLaunchKernelGGL(k_table_counts, gc, blk, 0, c->stream, nc, tkeys, C.A.indptr);
-    AMG_TRY(exclusive_scan_i32(c, C.A.indptr, int64_t(nc) + 1));
-    int32_t h2[2] = {0, 0};
-    AMG_HIP(hipMemcpyAsync(&h2[0], C.A.indptr + nc, 4, hipMemcpyDeviceToHost, c->stream));
-    AMG_HIP(hipMemcpyAsync(&h2[1], d_over, 4, hipMemcpyDeviceToHost, c->stream));
-    AMG_HIP(hipStreamSynchronize(c->stream));
-    if (h2[1]) {  // a coarse row has more than kTableCap neighbours: stop coarsening here
+    int nc = 0;
+    AMG_TRY(aggregate(c, F, d_flag, &nc));
+    if (nc <= 0 || nc > 0.8 * F.n) {  // nothing (left) to coarsen
       F.agg = nullptr;
       break;
     }
+    AmgLevel C;
+    C.n = nc;
+    int32_t* tkeys = nullptr;
+    double* tvals = nullptr;
+    AMG_TRY(c->arena.get(size_t(nc) * kRowCap, &tkeys));
+    AMG_TRY(c->arena.get(size_t(nc) * kRowCap, &tvals));
+    AMG_TRY(c->arena.get(size_t(nc) + 1, &C.A.indptr));
+    AMG_HIP(hipMemsetAsync(C.A.indptr + nc, 0, 4, c->stream));
+    AMG_HIP(hipMemsetAsync(d_flag + 1, 0, 4, c->stream));
+    hipLaunchKernelGGL(k_galerkin_rows, dim3(ceil_div(nc, 64)), dim3(64), 0, c->stream, nc, F.mptr,
+                       F.members, F.A.indptr, F.A.indices, F.A.vals, F.agg, C.A.indptr, tkeys, tvals,
+                       d_flag + 1);
+    AMG_TRY(exclusive_scan_i32(c, C.A.indptr, int64_t(nc) + 1));
+    int32_t h2[2] = {0, 0};
+    AMG_HIP(hipMemcpyAsync(&h2[0], C.A.indptr + nc, 4, hipMemcpyDeviceToHost, c->stream));
+    AMG_HIP(hipMemcpyAsync(&h2[1], d_flag + 1, 4, hipMemcpyDeviceToHost, c->stream));
+    AMG_HIP(hipStreamSynchronize(c->stream));
+    if (h2[1]) {  // a coarse row has more than kRowCap neighbours: stop coarsening here
+      F.agg = nullptr;
+      break;
+    }
+    const dim3 gc(ceil_div(nc, 256)), blk(256);
     AMG_TRY(c->arena.get(size_t(h2[0]) + 1, &C.A.indices));
     AMG_TRY(c->arena.get(size_t(h2[0]) + 1, &C.A.vals));
-    hipLaunchKernelGGL(k_table_to_csr, gc, blk, 0, c->stream, nc, tkeys, tvals, C.A.indptr,
-                       C.A.indices, C.A.vals);
+    hipLaunchKernelGGL(k_rows_to_csr, gc, blk, 0, c->stream, nc, tkeys, tvals, C.A.indptr, C.A.indices,
+                       C.A.vals);
+    AMG_TRY(c->arena.get(size_t(nc), &C.diag));
     AMG_TRY(c->arena.get(size_t(nc), &C.dinv));
-    hipLaunchKernelGGL(k_l1_diag, gc, blk, 0, c->stream, nc, C.A.indptr, C.A.vals, C.dinv);
+    hipLaunchKernelGGL(k_diag_l1, gc, blk, 0, c->stream, nc, C.A.indptr, C.A.indices, C.A.vals, C.diag,
+                       C.dinv);
     AMG_HIP(hipGetLastError());
     AMG_TRY(alloc_vectors(c, C, true));
     H->lv.push_back(C);
-    for (int a = 0; a < 3; ++a) dims[a] = (dims[a] + 1) / 2;
   }
   AmgLevel& last = H->lv.back();
   last.agg = nullptr;
   if (last.n <= kCoarseMax && H->lv.size() > 1) {
     H->nc = last.n;
     AMG_TRY(coarse_inverse(c, last, &H->dense_inv));
+  }
+  if (getenv("PYQSM_LBC_TRACE")) {
+    fprintf(stderr, "multigrid levels:");
+    for (auto& l : H->lv) fprintf(stderr, " %d", l.n);
+    fprintf(stderr, "\n");
   }
   *out = H;
   return 0;
@@ -468,52 +666,45 @@ void amg_destroy(AmgHierarchy* h) { delete h; }
 
 int amg_levels(const AmgHierarchy* h) { return h ? int(h->lv.size()) : 0; }
 
-int amg_vcycle(Ctx* c, AmgHierarchy* H, const double* b, double* x) {
+int amg_vcycle(Ctx* c, AmgHierarchy* H, const double* b, double* x, double* dot) {
   const int nl = int(H->lv.size());
   const dim3 blk(256);
-  // downward sweep
+  // downward sweep: pre-smooth, residual, restrict
   for (int l = 0; l < nl; ++l) {
     AmgLevel& L = H->lv[size_t(l)];
     const double* bl = l == 0 ? b : L.b;
-    double* xl = l == 0 ? x : L.x;
     const dim3 g(ceil_div(L.n, 256));
-    if (l == nl - 1 && H->dense_inv) {
-      hipLaunchKernelGGL(k_dense_solve, dim3(1), dim3(128), 0, c->stream, L.n, H->dense_inv, bl, xl);
-      break;
-    }
-    hipLaunchKernelGGL(k_smooth0, g, blk, 0, c->stream, L.n, L.dinv, bl, xl);
-    for (int sw = 1; sw < H->sweeps && l < nl - 1; ++sw) {
-      hipLaunchKernelGGL(k_residual, g, blk, 0, c->stream, L.n, L.A.indptr, L.A.indices, L.A.vals, bl,
-                         xl, L.r);
-      hipLaunchKernelGGL(k_correct, g, blk, 0, c->stream, L.n, L.dinv, L.r, xl);
-    }
-    if (l == nl - 1) {  // coarsest without a dense solve: a few more sweeps
-      for (int s = 0; s < 4; ++s) {
-        hipLaunchKernelGGL(k_residual, g, blk, 0, c->stream, L.n, L.A.indptr, L.A.indices, L.A.vals,
-                           bl, xl, L.r);
-        hipLaunchKernelGGL(k_correct, g, blk, 0, c->stream, L.n, L.dinv, L.r, xl);
+    if (l == nl - 1) {
+      double* xl = l == 0 ? x : L.xb;
+      if (H->dense_inv) {
+        hipLaunchKernelGGL(k_dense_solve, dim3(1), dim3(128), 0, c->stream, L.n, H->dense_inv, bl, xl);
+      } else {  // kTailSweeps (even) l1-Jacobi sweeps, ending in xl
+        double* other = L.xa;
+        hipLaunchKernelGGL(k_scale, g, blk, 0, c->stream, L.n, L.dinv, bl, xl);
+        for (int s = 0; s < kTailSweeps; s += 2) {
+          hipLaunchKernelGGL(k_sweep, g, blk, 0, c->stream, L.n, L.A.indptr, L.A.indices, L.A.vals,
+                             L.dinv, bl, xl, other);
+          hipLaunchKernelGGL(k_sweep, g, blk, 0, c->stream, L.n, L.A.indptr, L.A.indices, L.A.vals,
+                             L.dinv, bl, other, xl);
+        }
       }
       break;
     }
-    hipLaunchKernelGGL(k_residual, g, blk, 0, c->stream, L.n, L.A.indptr, L.A.indices, L.A.vals, bl,
-                       xl, L.r);
     AmgLevel& C = H->lv[size_t(l) + 1];
-    PQ_HIP(hipMemsetAsync(C.b, 0, size_t(C.n) * 24, c->stream));
-    hipLaunchKernelGGL(k_restrict, g, blk, 0, c->stream, L.n, L.agg, L.r, C.b);
+    hipLaunchKernelGGL(k_down, g, blk, 0, c->stream, L.n, L.A.indptr, L.A.indices, L.A.vals, L.dinv, bl,
+                       L.xa, L.r);
+    hipLaunchKernelGGL(k_restrict, dim3(ceil_div(C.n, 256)), blk, 0, c->stream, C.n, L.mptr, L.members,
+                       L.r, C.b);
   }
-  // upward sweep
+  // upward sweep: coarse correction + post-smoothing
   for (int l = nl - 2; l >= 0; --l) {
     AmgLevel& L = H->lv[size_t(l)];
     AmgLevel& C = H->lv[size_t(l) + 1];
     const double* bl = l == 0 ? b : L.b;
-    double* xl = l == 0 ? x : L.x;
-    const dim3 g(ceil_div(L.n, 256));
-    hipLaunchKernelGGL(k_prolong_add, g, blk, 0, c->stream, L.n, L.agg, C.x, H->alpha, xl);
-    for (int sw = 0; sw < H->sweeps; ++sw) {
-      hipLaunchKernelGGL(k_residual, g, blk, 0, c->stream, L.n, L.A.indptr, L.A.indices, L.A.vals, bl,
-                         xl, L.r);
-      hipLaunchKernelGGL(k_correct, g, blk, 0, c->stream, L.n, L.dinv, L.r, xl);
-    }
+    double* xl = l == 0 ? x : L.xb;
+    hipLaunchKernelGGL(k_up, dim3(ceil_div(L.n, 256)), blk, 0, c->stream, L.n, L.A.indptr, L.A.indices,
+                       L.A.vals, L.dinv, L.agg, C.xb, bl, L.xa, xl,
+                       l == 0 ? dot : static_cast<double*>(nullptr));
   }
   PQ_HIP(hipGetLastError());
   return 0;

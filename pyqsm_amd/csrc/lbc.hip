@@ -67,29 +67,6 @@ __global__ __launch_bounds__(256) void k_diag(int n, const int32_t* __restrict__
   minv[i] = d > 0.0 ? 1.0 / d : 1.0;
 }
 
-// Block reduction of three partial sums followed by one fp64 atomic per column.
-__device__ __forceinline__ void reduce3_atomic(double v0, double v1, double v2, double* out) {
-  __shared__ double red[3][4];
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    v0 += __shfl_down(v0, off, 64);
-    v1 += __shfl_down(v1, off, 64);
-    v2 += __shfl_down(v2, off, 64);
-  }
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  if (lane == 0) {
-    red[0][w] = v0;
-    red[1][w] = v1;
-    red[2][w] = v2;
-  }
-  __syncthreads();
-  if (threadIdx.x < 3) {
-    double t = (red[threadIdx.x][0] + red[threadIdx.x][1]) +
-               (red[threadIdx.x][2] + red[threadIdx.x][3]);
-    atomicAdd(out + threadIdx.x, t);
-  }
-}
-
 // Scalars of the fused Jacobi-PCG, kept on the device. Two slots alternate with
 // the iteration parity p: rz[p] is the current r.z, rz[p^1] collects the next one;
 // each kernel clears the slot that the following kernels will accumulate into, so
@@ -452,6 +429,7 @@ static int jacobi_pcg(Ctx* c, const System& S, const Work& w, const double* b, d
   int it = 0, best_it = 0;
   bool broke = false;
   hipGraphExec_t exec = nullptr;
+  if (getenv("PYQSM_NO_GRAPH")) cache = nullptr;
   while (!done && it < max_it) {
     // bursts have an even length so that each one starts at parity 0
     int burst = std::min<int>(kBurst, max_it - it);
@@ -521,40 +499,90 @@ static int dot3_host(Ctx* c, int n, const double* a, const double* b, double* d_
 }
 
 
-// CG on B y = rhs preconditioned by one multigrid V-cycle; scalars on the host
-// (a few dozen iterations, each dominated by the cycle). y starts at 0.
+// alpha = rz/pq ; x += alpha dir ; r -= alpha q ; rr += r.r   (the multigrid cycle follows)
+__global__ __launch_bounds__(256) void k_update_r(int n, const double* __restrict__ dir,
+                                                  const double* __restrict__ q,
+                                                  double* __restrict__ x, double* __restrict__ r,
+                                                  Scal* __restrict__ sc, int par) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  double rr[3] = {0, 0, 0};
+  if (i < n) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const double pqk = sc->pq[par][k];
+      const double alpha = pqk != 0.0 ? sc->rz[par][k] / pqk : 0.0;
+      x[3 * i + k] += alpha * dir[3 * i + k];
+      const double ri = r[3 * i + k] - alpha * q[3 * i + k];
+      r[3 * i + k] = ri;
+      rr[k] = ri * ri;
+    }
+  }
+  reduce3_atomic(rr[0], rr[1], rr[2], sc->rr[par]);
+}
+
+static constexpr int kAmgBurst = 2;  // iterations per graph replay / residual check
+
+// CG on B y = rhs preconditioned by one multigrid V-cycle (amg.hip). Same device-side
+// scalar protocol as jacobi_pcg: an iteration is the sparse pass, the update, the cycle
+// (its last kernel also accumulates r.z) and the direction update, replayed as a graph
+// two iterations at a time; the host only reads |r|^2 between replays. y starts at 0.
 static int amg_pcg(Ctx* c, const System& S, const Work& w, AmgHierarchy* H, const double* rhs,
-                   double* y, double rtol, int32_t max_it, double* d_tmp, int32_t* iters,
+                   double* y, double rtol, int32_t max_it, GraphCache* cache, int32_t* iters,
                    double resid[3]) {
   const int N = S.n;
   const dim3 grid(ceil_div(N, 256)), block(256);
-  double *r = w.r, *z = w.z, *p = w.dir, *q = w.q;
+  PQ_HIP(hipMemsetAsync(w.sc, 0, sizeof(Scal), c->stream));
   PQ_HIP(hipMemsetAsync(y, 0, size_t(N) * 24, c->stream));
-  PQ_HIP(hipMemcpyAsync(r, rhs, size_t(N) * 24, hipMemcpyDeviceToDevice, c->stream));
-  double bb[3], rr[3], rz[3], pq[3];
-  PQ_TRY(dot3_host(c, N, rhs, rhs, d_tmp, bb));
-  PQ_TRY(amg_vcycle(c, H, r, z));
-  PQ_HIP(hipMemcpyAsync(p, z, size_t(N) * 24, hipMemcpyDeviceToDevice, c->stream));
-  PQ_TRY(dot3_host(c, N, r, z, d_tmp, rz));
+  PQ_HIP(hipMemcpyAsync(w.r, rhs, size_t(N) * 24, hipMemcpyDeviceToDevice, c->stream));
+  hipLaunchKernelGGL(k_dot3, grid, block, 0, c->stream, N, rhs, rhs, w.sc->bb);
+  PQ_TRY(amg_vcycle(c, H, w.r, w.z, w.sc->rz[0]));
+  PQ_HIP(hipMemcpyAsync(w.dir, w.z, size_t(N) * 24, hipMemcpyDeviceToDevice, c->stream));
+  double bb[3];
+  PQ_HIP(hipMemcpyAsync(bb, w.sc->bb, 24, hipMemcpyDeviceToHost, c->stream));
+  PQ_HIP(hipStreamSynchronize(c->stream));
+  for (int k = 0; k < 3; ++k) resid[k] = bb[k] > 0 ? 1.0 : 0.0;
+  *iters = 0;
+  if (bb[0] == 0.0 && bb[1] == 0.0 && bb[2] == 0.0) return 0;
+  auto iteration = [&](int par) -> int {
+    hipLaunchKernelGGL(k_spmv3_tail<OP_B>, grid, block, 0, c->stream, N, S.L.indptr, S.L.indices,
+                       S.L.vals, w.dir, static_cast<const double*>(nullptr), S.c, S.wh, w.dir, w.q,
+                       w.sc, par);
+    hipLaunchKernelGGL(k_update_r, grid, block, 0, c->stream, N, w.dir, w.q, y, w.r, w.sc, par);
+    PQ_TRY(amg_vcycle(c, H, w.r, w.z, w.sc->rz[par ^ 1]));
+    hipLaunchKernelGGL(k_direction, grid, block, 0, c->stream, N, w.z, w.dir, w.sc, par);
+    return 0;
+  };
+  hipGraphExec_t exec = nullptr;
+  if (getenv("PYQSM_NO_GRAPH")) cache = nullptr;  // plain launches (profilers that cannot follow graphs)
+  if (cache)
+    for (auto& g : cache->items)
+      if (g.b == static_cast<const void*>(H) && g.x == y && g.op == 2) exec = g.exec;
   int it = 0;
   bool done = false;
-  for (int k = 0; k < 3; ++k) resid[k] = bb[k] > 0 ? 1.0 : 0.0;
-  if (bb[0] == 0.0 && bb[1] == 0.0 && bb[2] == 0.0) done = true;
   while (!done && it < max_it) {
-    ProfScope ps(c, "lbc_amg_iter");
-    hipLaunchKernelGGL(k_spmv3_tail<OP_B>, grid, block, 0, c->stream, N, S.L.indptr, S.L.indices,
-                       S.L.vals, p, static_cast<const double*>(nullptr), S.c, S.wh, p, q,
-                       static_cast<Scal*>(nullptr), 0);
-    PQ_TRY(dot3_host(c, N, p, q, d_tmp, pq));
-    S3 alpha, nalpha;
-    for (int k = 0; k < 3; ++k) {
-      alpha.v[k] = pq[k] > 0.0 ? rz[k] / pq[k] : 0.0;
-      nalpha.v[k] = -alpha.v[k];
+    {
+      ProfScope ps(c, "lbc_amg_iter", kAmgBurst);
+      if (cache && !exec) {
+        hipGraph_t graph = nullptr;
+        PQ_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
+        int rc = 0;
+        for (int bi = 0; bi < kAmgBurst && rc == 0; ++bi) rc = iteration(bi & 1);
+        PQ_HIP(hipStreamEndCapture(c->stream, &graph));
+        if (rc != 0) return rc;
+        PQ_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        (void)hipGraphDestroy(graph);
+        cache->items.push_back({static_cast<const void*>(H), y, 2, exec});
+      }
+      if (exec) {
+        PQ_HIP(hipGraphLaunch(exec, c->stream));
+      } else {
+        for (int bi = 0; bi < kAmgBurst; ++bi) PQ_TRY(iteration(bi & 1));
+      }
     }
-    hipLaunchKernelGGL(k_axpy3, grid, block, 0, c->stream, N, alpha, p, y);
-    hipLaunchKernelGGL(k_axpy3, grid, block, 0, c->stream, N, nalpha, q, r);
-    PQ_TRY(dot3_host(c, N, r, r, d_tmp, rr));
-    ++it;
+    it += kAmgBurst;
+    double rr[3];
+    PQ_HIP(hipMemcpyAsync(rr, &w.sc->rr[1][0], 24, hipMemcpyDeviceToHost, c->stream));
+    PQ_HIP(hipStreamSynchronize(c->stream));
     done = true;
     for (int k = 0; k < 3; ++k) {
       resid[k] = bb[k] > 0 ? std::sqrt(rr[k] / bb[k]) : 0.0;
@@ -564,16 +592,6 @@ static int amg_pcg(Ctx* c, const System& S, const Work& w, AmgHierarchy* H, cons
         return fail(PYQSM_ENOCONV, "multigrid CG broke down after %d iterations", it);
       }
     }
-    if (done) break;
-    PQ_TRY(amg_vcycle(c, H, r, z));
-    double rz_new[3];
-    PQ_TRY(dot3_host(c, N, r, z, d_tmp, rz_new));
-    S3 beta;
-    for (int k = 0; k < 3; ++k) {
-      beta.v[k] = rz[k] != 0.0 ? rz_new[k] / rz[k] : 0.0;
-      rz[k] = rz_new[k];
-    }
-    hipLaunchKernelGGL(k_xpay3, grid, block, 0, c->stream, N, beta, z, p);
   }
   PQ_HIP(hipGetLastError());
   *iters = it;
@@ -625,15 +643,14 @@ int lbc_solve_device(Ctx* c, const DevCsr& L, int64_t n, const double* wl, doubl
   hipLaunchKernelGGL(k_diag_b, grid, block, 0, c->stream, N, L.indptr, L.indices, L.vals,
                      wl_uniform, wh, minv_b);
   System SB{L, N, OP_B, nullptr, wl_uniform, wh, minv_b};
-  // Optional multilevel preconditioner for the B-solves (PYQSM_AMG=1). Measured on
-  // the synthetic forests it cuts the iteration count 7-10x but each cycle costs
-  // ~40 launches, and with purely geometric aggregation it still needs ~200 cycles
-  // per solve, so Jacobi-PCG stays the default (DESIGN.md "Contraction solve").
+  // Multilevel preconditioner for the B-solves (amg.hip): 12-17 cycles per solve where
+  // Jacobi-PCG needs 200-700 sparse passes. PYQSM_AMG=0 selects Jacobi-PCG; it is also
+  // the fallback when no hierarchy can be built (tiny or fully decoupled systems).
   AmgHierarchy* amg = nullptr;
   const char* amg_env = getenv("PYQSM_AMG");
-  if (amg_env && amg_env[0] == '1') {
+  if (!(amg_env && amg_env[0] == '0')) {
     ProfScope ps(c, "lbc_amg_build");
-    if (amg_build(c, L, N, wl_uniform, wh, pts, &amg) != 0 || amg_levels(amg) < 2) {
+    if (amg_build(c, L, N, wl_uniform, wh, &amg) != 0 || amg_levels(amg) < 2) {
       amg_destroy(amg);
       amg = nullptr;
     }
@@ -655,10 +672,10 @@ int lbc_solve_device(Ctx* c, const DevCsr& L, int64_t n, const double* wl, doubl
     int32_t it1 = 0, it2 = 0;
     double rs[3];
     if (amg) {
-      int rc = amg_pcg(c, SB, wb, amg, rhs, y, kInnerRtol, std::min(budget(), kAmgMaxIt), d_tmp, &it1, rs);
+      int rc = amg_pcg(c, SB, wb, amg, rhs, y, kInnerRtol, std::min(budget(), kAmgMaxIt), &cache, &it1, rs);
       if (rc != 0 && rc != PYQSM_ENOCONV) return rc;
       total_inner += it1;
-      rc = amg_pcg(c, SB, wb, amg, y, out, kInnerRtol, std::min(budget(), kAmgMaxIt), d_tmp, &it2, rs);
+      rc = amg_pcg(c, SB, wb, amg, y, out, kInnerRtol, std::min(budget(), kAmgMaxIt), &cache, &it2, rs);
       if (rc != 0 && rc != PYQSM_ENOCONV) return rc;
       total_inner += it2;
       return 0;

@@ -10,19 +10,41 @@ struct DevCsr {
   double* vals;
 };
 
+// Block reduction of three partial sums followed by one fp64 atomic per column.
+__device__ __forceinline__ void reduce3_atomic(double v0, double v1, double v2, double* out) {
+  __shared__ double red[3][4];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    v0 += __shfl_down(v0, off, 64);
+    v1 += __shfl_down(v1, off, 64);
+    v2 += __shfl_down(v2, off, 64);
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) {
+    red[0][w] = v0;
+    red[1][w] = v1;
+    red[2][w] = v2;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    double t = (red[threadIdx.x][0] + red[threadIdx.x][1]) +
+               (red[threadIdx.x][2] + red[threadIdx.x][3]);
+    atomicAdd(out + threadIdx.x, t);
+  }
+}
+
 // Aggregation multigrid for B = c*L + diag(wh) (amg.hip). Opaque to callers.
 struct AmgHierarchy;
 
-// Builds the hierarchy for the n-point system; `xyz` (f64 [n,3], device) are the
-// current positions and only steer which points are aggregated together. All
-// device memory comes from the context arena (valid until the next arena reset).
-int amg_build(Ctx* c, const DevCsr& L, int n, double cw, const double* wh, const double* xyz,
-              AmgHierarchy** out);
+// Builds the hierarchy for B = cw*L + diag(wh) of the n-point system. All device
+// memory comes from the context arena (valid until the next arena reset).
+int amg_build(Ctx* c, const DevCsr& L, int n, double cw, const double* wh, AmgHierarchy** out);
 void amg_destroy(AmgHierarchy* h);
 int amg_levels(const AmgHierarchy* h);
 
 // x = M^-1 b for three columns: one symmetric V(1,1) cycle (l1-Jacobi smoothing,
-// piecewise-constant aggregation, dense solve on the coarsest level).
-int amg_vcycle(Ctx* c, AmgHierarchy* h, const double* b, double* x);
+// piecewise-constant strength-based aggregation, dense solve on the coarsest level).
+// When `dot` is given, dot[0..2] += b . x per column (fused into the last kernel).
+int amg_vcycle(Ctx* c, AmgHierarchy* h, const double* b, double* x, double* dot = nullptr);
 
 }  // namespace pyqsm
