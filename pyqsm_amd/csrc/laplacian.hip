@@ -443,18 +443,56 @@ __device__ __host__ inline bool flip_candidate(int h, const double* fl, const in
   return true;
 }
 
-// Round part 1: every candidate claims its two faces and their four outer
-// neighbours with its priority (half-edge id + 1); the largest priority wins a face.
-__global__ __launch_bounds__(256) void k_flip_claim(int H, const double* __restrict__ fl,
-                                                    const int32_t* __restrict__ fn,
-                                                    int32_t* __restrict__ claim,
-                                                    int32_t* __restrict__ n_cand) {
+// ---- flip rounds over a work list ---------------------------------------------------
+// Only edges next to a flip can change their Delaunay status, so after the seeding pass
+// the rounds walk a list of half-edges instead of the whole cover: a round is the
+// candidates of the list claiming their six faces, the owners flipping, and the next
+// list = the losers + the five edges of every flipped quad (deduplicated by a round
+// stamp). The winners of a round are the same as with a full scan (priorities are the
+// half-edge ids), so the sequence of flips — and the result — does not depend on it.
+
+// Every lane contributes `cnt` slots; returns this lane's first slot in the list.
+__device__ __forceinline__ int wave_reserve(int cnt, int32_t* counter) {
+  int incl = cnt;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int v = __shfl_up(incl, off, 64);
+    if ((threadIdx.x & 63) >= off) incl += v;
+  }
+  const int total = __shfl(incl, 63, 64);
+  int base = 0;
+  if ((threadIdx.x & 63) == 0 && total > 0) base = atomicAdd(counter, total);
+  base = __shfl(base, 0, 64);
+  return base + incl - cnt;
+}
+
+__global__ __launch_bounds__(256) void k_flip_seed(int H, const double* __restrict__ fl,
+                                                   const int32_t* __restrict__ fn,
+                                                   int32_t* __restrict__ list,
+                                                   int32_t* __restrict__ count) {
   int h = blockIdx.x * 256 + threadIdx.x;
-  if (h >= H) return;
   FlipInfo q;
-  if (!flip_candidate(h, fl, fn, &q)) return;
-  atomicAdd(n_cand, 1);
-  const int pr = h + 1;
+  const bool cand = h < H && flip_candidate(h, fl, fn, &q);
+  const int slot = wave_reserve(cand ? 1 : 0, count);
+  if (cand) list[slot] = h;
+}
+
+// Round part 1: every candidate of the list claims its two faces and their four outer
+// neighbours; the claim carries the round in its upper half, so claims never need clearing.
+__global__ __launch_bounds__(256) void k_flip_claim(int m, const int32_t* __restrict__ list,
+                                                    unsigned long long stamp,
+                                                    const double* __restrict__ fl,
+                                                    const int32_t* __restrict__ fn,
+                                                    unsigned long long* __restrict__ claim,
+                                                    uint8_t* __restrict__ is_cand) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= m) return;
+  const int h = list[i];
+  FlipInfo q;
+  const bool cand = flip_candidate(h, fl, fn, &q);
+  is_cand[i] = cand;
+  if (!cand) return;
+  const unsigned long long pr = stamp | (unsigned long long)(h + 1);
   atomicMax(&claim[q.f], pr);
   atomicMax(&claim[q.g], pr);
   atomicMax(&claim[fn[3 * size_t(q.f) + nx3(q.c)] / 3], pr);
@@ -466,51 +504,93 @@ __global__ __launch_bounds__(256) void k_flip_claim(int H, const double* __restr
 // Round part 2: a candidate that owns all six faces flips its edge.
 //   before: f = (a, b, k) with edge c = a->b,   g = (b, a, l) with edge d = b->a
 //   after:  f = (a, l, k),  g = (b, k, l)       (new edge l->k in f, k->l in g)
-__global__ __launch_bounds__(256) void k_flip_apply(int H, int32_t* __restrict__ fv,
+// A candidate that lost stays on the list; a flip puts its five edges on it.
+__global__ __launch_bounds__(256) void k_flip_apply(int m, const int32_t* __restrict__ list,
+                                                    const uint8_t* __restrict__ is_cand,
+                                                    unsigned long long stamp, int round_id,
+                                                    int32_t* __restrict__ fv,
                                                     double* __restrict__ fl,
                                                     int32_t* __restrict__ fn,
-                                                    const int32_t* __restrict__ claim,
-                                                    int32_t* __restrict__ n_done) {
-  int h = blockIdx.x * 256 + threadIdx.x;
-  if (h >= H) return;
-  FlipInfo q;
-  if (!flip_candidate(h, fl, fn, &q)) return;
-  const int pr = h + 1;
-  const int f = q.f, c = q.c, g = q.g, d = q.d;
-  int n_bk = fn[3 * size_t(f) + nx3(c)], n_ka = fn[3 * size_t(f) + pv3(c)];
-  int n_al = fn[3 * size_t(g) + nx3(d)], n_lb = fn[3 * size_t(g) + pv3(d)];
-  if (claim[f] != pr || claim[g] != pr || claim[n_bk / 3] != pr || claim[n_ka / 3] != pr ||
-      claim[n_al / 3] != pr || claim[n_lb / 3] != pr)
-    return;
-  const int a = fv[3 * size_t(f) + c], b = fv[3 * size_t(f) + nx3(c)],
-            k = fv[3 * size_t(f) + pv3(c)], l = fv[3 * size_t(g) + pv3(d)];
-  // outer edges that are glued to f or g themselves move with the flip
-  const int old_bk = 3 * f + nx3(c), old_ka = 3 * f + pv3(c), old_al = 3 * g + nx3(d),
-            old_lb = 3 * g + pv3(d);
-  auto remap = [&](int code) {
-    if (code == old_bk) return 3 * g + 0;
-    if (code == old_ka) return 3 * f + 2;
-    if (code == old_al) return 3 * f + 0;
-    if (code == old_lb) return 3 * g + 2;
-    return code;
-  };
-  n_bk = remap(n_bk);
-  n_ka = remap(n_ka);
-  n_al = remap(n_al);
-  n_lb = remap(n_lb);
-  fv[3 * size_t(f)] = a; fv[3 * size_t(f) + 1] = l; fv[3 * size_t(f) + 2] = k;
-  fl[3 * size_t(f)] = q.lal; fl[3 * size_t(f) + 1] = q.lkl; fl[3 * size_t(f) + 2] = q.lka;
-  fn[3 * size_t(f)] = n_al; fn[3 * size_t(f) + 1] = 3 * g + 1; fn[3 * size_t(f) + 2] = n_ka;
-  fv[3 * size_t(g)] = b; fv[3 * size_t(g) + 1] = k; fv[3 * size_t(g) + 2] = l;
-  fl[3 * size_t(g)] = q.lbk; fl[3 * size_t(g) + 1] = q.lkl; fl[3 * size_t(g) + 2] = q.llb;
-  fn[3 * size_t(g)] = n_bk; fn[3 * size_t(g) + 1] = 3 * f + 1; fn[3 * size_t(g) + 2] = n_lb;
-  // back links of the outer neighbours (for neighbours inside {f, g} the forward
-  // links written above already point the right way)
-  if (n_al / 3 != f && n_al / 3 != g) fn[n_al] = 3 * f + 0;
-  if (n_ka / 3 != f && n_ka / 3 != g) fn[n_ka] = 3 * f + 2;
-  if (n_bk / 3 != f && n_bk / 3 != g) fn[n_bk] = 3 * g + 0;
-  if (n_lb / 3 != f && n_lb / 3 != g) fn[n_lb] = 3 * g + 2;
-  atomicAdd(n_done, 1);
+                                                    const unsigned long long* __restrict__ claim,
+                                                    int32_t* __restrict__ mark,
+                                                    int32_t* __restrict__ next,
+                                                    int32_t* __restrict__ counts /*[0] next size, [1] flips*/) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  int push[5];
+  int np = 0;
+  bool flipped = false;
+  if (i < m && is_cand[i]) {
+    const int h = list[i];
+    const int f = h / 3, c = h % 3;
+    const unsigned long long pr = stamp | (unsigned long long)(h + 1);
+    // f and g first: while both are ours nobody else touches their links
+    bool mine = claim[f] == pr;
+    int g = 0, d = 0;
+    if (mine) {
+      const int hg = fn[h];
+      g = hg / 3;
+      d = hg % 3;
+      mine = claim[g] == pr;
+    }
+    int n_bk = 0, n_ka = 0, n_al = 0, n_lb = 0;
+    if (mine) {
+      n_bk = fn[3 * size_t(f) + nx3(c)];
+      n_ka = fn[3 * size_t(f) + pv3(c)];
+      n_al = fn[3 * size_t(g) + nx3(d)];
+      n_lb = fn[3 * size_t(g) + pv3(d)];
+      mine = claim[n_bk / 3] == pr && claim[n_ka / 3] == pr && claim[n_al / 3] == pr &&
+             claim[n_lb / 3] == pr;
+    }
+    if (!mine) {
+      push[np++] = h;
+    } else {
+      FlipInfo q;
+      (void)flip_candidate(h, fl, fn, &q);  // geometry of our own six faces: stable
+      const int a = fv[3 * size_t(f) + c], b = fv[3 * size_t(f) + nx3(c)],
+                k = fv[3 * size_t(f) + pv3(c)], l = fv[3 * size_t(g) + pv3(d)];
+      // outer edges that are glued to f or g themselves move with the flip
+      const int old_bk = 3 * f + nx3(c), old_ka = 3 * f + pv3(c), old_al = 3 * g + nx3(d),
+                old_lb = 3 * g + pv3(d);
+      auto remap = [&](int code) {
+        if (code == old_bk) return 3 * g + 0;
+        if (code == old_ka) return 3 * f + 2;
+        if (code == old_al) return 3 * f + 0;
+        if (code == old_lb) return 3 * g + 2;
+        return code;
+      };
+      n_bk = remap(n_bk);
+      n_ka = remap(n_ka);
+      n_al = remap(n_al);
+      n_lb = remap(n_lb);
+      fv[3 * size_t(f)] = a; fv[3 * size_t(f) + 1] = l; fv[3 * size_t(f) + 2] = k;
+      fl[3 * size_t(f)] = q.lal; fl[3 * size_t(f) + 1] = q.lkl; fl[3 * size_t(f) + 2] = q.lka;
+      fn[3 * size_t(f)] = n_al; fn[3 * size_t(f) + 1] = 3 * g + 1; fn[3 * size_t(f) + 2] = n_ka;
+      fv[3 * size_t(g)] = b; fv[3 * size_t(g) + 1] = k; fv[3 * size_t(g) + 2] = l;
+      fl[3 * size_t(g)] = q.lbk; fl[3 * size_t(g) + 1] = q.lkl; fl[3 * size_t(g) + 2] = q.llb;
+      fn[3 * size_t(g)] = n_bk; fn[3 * size_t(g) + 1] = 3 * f + 1; fn[3 * size_t(g) + 2] = n_lb;
+      // back links of the outer neighbours (for neighbours inside {f, g} the forward
+      // links written above already point the right way)
+      if (n_al / 3 != f && n_al / 3 != g) fn[n_al] = 3 * f + 0;
+      if (n_ka / 3 != f && n_ka / 3 != g) fn[n_ka] = 3 * f + 2;
+      if (n_bk / 3 != f && n_bk / 3 != g) fn[n_bk] = 3 * g + 0;
+      if (n_lb / 3 != f && n_lb / 3 != g) fn[n_lb] = 3 * g + 2;
+      flipped = true;
+      // every edge is listed under the smaller of its two half-edge ids
+      push[np++] = min(3 * f + 0, n_al);
+      push[np++] = min(3 * f + 2, n_ka);
+      push[np++] = min(3 * g + 0, n_bk);
+      push[np++] = min(3 * g + 2, n_lb);
+      push[np++] = min(3 * f + 1, 3 * g + 1);
+    }
+  }
+  // stamp-deduplicated append
+  int keep = 0;
+  for (int p = 0; p < np; ++p)
+    if (atomicExch(&mark[push[p]], round_id + 1) != round_id + 1) push[keep++] = push[p];
+  int slot = wave_reserve(keep, counts);
+  for (int p = 0; p < keep; ++p) next[slot++] = push[p];
+  const unsigned long long fb = __ballot(flipped);
+  if (fb != 0 && (threadIdx.x & 63) == 0) atomicAdd(counts + 1, __popcll(fb));
 }
 
 __global__ __launch_bounds__(256) void k_cover_vcount(int F, const int32_t* __restrict__ fv,
@@ -678,7 +758,9 @@ int pyqsm_pc_laplacian(const double* xyz, int64_t n, int32_t k, double moll, int
     PQ_HIP(hipMemcpyAsync(&T, d_tcount + n, 4, hipMemcpyDeviceToHost, c->stream));
     PQ_HIP(hipStreamSynchronize(c->stream));
     int32_t *d_tris, *d_vcount, *d_cursor, *d_nnzrow, *d_fv, *d_fn, *d_bcount, *d_bcursor,
-        *d_claim, *d_cnt;
+        *d_cnt, *d_mark, *d_list[2];
+    unsigned long long* d_claim;
+    uint8_t* d_iscand;
     double *d_len, *d_area, *d_blk_sum, *d_blk_slack, *d_eps, *d_mass, *d_fl;
     Entry* d_ent;
     EdgeRec* d_rec;
@@ -702,6 +784,10 @@ int pyqsm_pc_laplacian(const double* xyz, int64_t n, int32_t k, double moll, int
     PQ_TRY(c->arena.get(size_t(n), &d_bcursor));
     PQ_TRY(c->arena.get(size_t(T) * 3 + 1, &d_rec));
     PQ_TRY(c->arena.get(size_t(F) + 1, &d_claim));
+    PQ_TRY(c->arena.get(size_t(F) * 3 + 1, &d_mark));
+    PQ_TRY(c->arena.get(size_t(F) * 3 + 1, &d_list[0]));
+    PQ_TRY(c->arena.get(size_t(F) * 3 + 1, &d_list[1]));
+    PQ_TRY(c->arena.get(size_t(F) * 3 + 1, &d_iscand));
     PQ_TRY(c->arena.get(2, &d_cnt));
     PQ_HIP(hipMemsetAsync(d_vcount, 0, (size_t(n) + 1) * 4, c->stream));
     PQ_HIP(hipMemsetAsync(d_cursor, 0, size_t(n) * 4, c->stream));
@@ -729,17 +815,29 @@ int pyqsm_pc_laplacian(const double* xyz, int64_t n, int32_t k, double moll, int
       PQ_HIP(hipGetLastError());
       // intrinsic Delaunay flips: rounds of conflict-free flips until none is left
       ProfScope pf(c, "lap_flips");
-      for (int round = 0; round < kMaxFlipRounds; ++round) {
-        PQ_HIP(hipMemsetAsync(d_claim, 0, (size_t(F) + 1) * 4, c->stream));
+      PQ_HIP(hipMemsetAsync(d_claim, 0, (size_t(F) + 1) * 8, c->stream));
+      PQ_HIP(hipMemsetAsync(d_mark, 0, (size_t(F) * 3 + 1) * 4, c->stream));
+      PQ_HIP(hipMemsetAsync(d_cnt, 0, 8, c->stream));
+      hipLaunchKernelGGL(k_flip_seed, gh, blk, 0, c->stream, 3 * F, d_fl, d_fn, d_list[0], d_cnt);
+      int32_t hc[2] = {0, 0};
+      PQ_HIP(hipMemcpyAsync(hc, d_cnt, 8, hipMemcpyDeviceToHost, c->stream));
+      PQ_HIP(hipStreamSynchronize(c->stream));
+      int m = hc[0];
+      for (int round = 0; round < kMaxFlipRounds && m > 0; ++round) {
+        const int32_t* cur = d_list[round & 1];
+        int32_t* nxt = d_list[(round & 1) ^ 1];
+        const unsigned long long stamp = (unsigned long long)(round + 1) << 32;
+        const dim3 gm(ceil_div(m, 256));
         PQ_HIP(hipMemsetAsync(d_cnt, 0, 8, c->stream));
-        hipLaunchKernelGGL(k_flip_claim, gh, blk, 0, c->stream, 3 * F, d_fl, d_fn, d_claim, d_cnt);
-        hipLaunchKernelGGL(k_flip_apply, gh, blk, 0, c->stream, 3 * F, d_fv, d_fl, d_fn, d_claim,
-                           d_cnt + 1);
+        hipLaunchKernelGGL(k_flip_claim, gm, blk, 0, c->stream, m, cur, stamp, d_fl, d_fn, d_claim,
+                           d_iscand);
+        hipLaunchKernelGGL(k_flip_apply, gm, blk, 0, c->stream, m, cur, d_iscand, stamp, round, d_fv,
+                           d_fl, d_fn, d_claim, d_mark, nxt, d_cnt);
         PQ_HIP(hipGetLastError());
-        int32_t hc[2] = {0, 0};
         PQ_HIP(hipMemcpyAsync(hc, d_cnt, 8, hipMemcpyDeviceToHost, c->stream));
         PQ_HIP(hipStreamSynchronize(c->stream));
-        if (hc[0] == 0 || hc[1] == 0) break;  // nothing left to flip (or nothing could be flipped)
+        if (hc[1] == 0) break;  // nothing could be flipped
+        m = hc[0];
       }
       hipLaunchKernelGGL(k_cover_vcount, gf, blk, 0, c->stream, F, d_fv, d_vcount);
     }
