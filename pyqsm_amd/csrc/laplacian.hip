@@ -638,13 +638,93 @@ __device__ __forceinline__ bool ent_less(const Entry& a, const Entry& b) {
   return a.col < b.col || (a.col == b.col && a.key < b.key);
 }
 
-// Per row: insertion-sort the contributions by (col, key), then either count the
-// distinct columns (pass 0) or write the merged row with its diagonal (pass 1).
-template <int PASS>
+// Sort the contributions of every row by (col, key) and count its distinct columns:
+// one wave per row, rank sort in registers (lane l holds entries l, l+64, ...; every
+// entry is broadcast once and compared by all lanes), so a 70-entry row costs ~70
+// broadcasts instead of ~1200 dependent global-memory moves of a per-lane insertion sort.
+static constexpr int kSortPer = 8;  // rows up to 64 * kSortPer entries take the wave path
+
+__global__ __launch_bounds__(256) void k_sort_rows(int n, const int32_t* __restrict__ row_start,
+                                                   Entry* __restrict__ ent,
+                                                   int32_t* __restrict__ nnz_row) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;  // wave-uniform
+  const int b = row_start[i], e = row_start[i + 1], m = e - b;
+  if (m > 64 * kSortPer) {  // very long row: serial insertion sort by one lane
+    if (lane == 0) {
+      for (int a = b + 1; a < e; ++a) {
+        const Entry x = ent[a];
+        int j = a;
+        while (j > b && ent_less(x, ent[j - 1])) {
+          ent[j] = ent[j - 1];
+          --j;
+        }
+        ent[j] = x;
+      }
+      int distinct = 0;
+      for (int a = b; a < e; ++a)
+        if (ent[a].col != i && (a == b || ent[a].col != ent[a - 1].col)) ++distinct;
+      nnz_row[i] = distinct + 1;
+    }
+    return;
+  }
+  const int chunks = (m + 63) >> 6;
+  int col[kSortPer], key[kSortPer], rank[kSortPer];
+  double val[kSortPer];
+  bool first[kSortPer];
+#pragma unroll
+  for (int t = 0; t < kSortPer; ++t) {
+    const int idx = lane + 64 * t;
+    col[t] = 0x7FFFFFFF;
+    key[t] = 0x7FFFFFFF;
+    val[t] = 0.0;
+    rank[t] = 0;
+    first[t] = true;
+    if (t < chunks && idx < m) {
+      const Entry x = ent[b + idx];
+      col[t] = x.col;
+      key[t] = x.key;
+      val[t] = x.val;
+    }
+  }
+#pragma unroll
+  for (int cj = 0; cj < kSortPer; ++cj) {
+    if (cj < chunks) {
+      const int cnt = min(64, m - 64 * cj);
+      for (int l = 0; l < cnt; ++l) {
+        const int oc = __builtin_amdgcn_readlane(col[cj], l);
+        const int ok = __builtin_amdgcn_readlane(key[cj], l);
+#pragma unroll
+        for (int t = 0; t < kSortPer; ++t) {
+          if (t < chunks) {
+            // (col, key) can repeat (both ends of a loop edge of the flipped cover): ties
+            // keep their input order, so ranks stay a permutation
+            const bool same = oc == col[t];
+            const bool less = oc < col[t] || (same && (ok < key[t] || (ok == key[t] && 64 * cj + l < lane + 64 * t)));
+            rank[t] += less ? 1 : 0;
+            if (same && less) first[t] = false;
+          }
+        }
+      }
+    }
+  }
+  int distinct = 0;
+#pragma unroll
+  for (int t = 0; t < kSortPer; ++t) {
+    if (t < chunks) {
+      const bool valid = lane + 64 * t < m;
+      if (valid) ent[b + rank[t]] = Entry{col[t], key[t], val[t]};
+      distinct += __popcll(__ballot(valid && first[t] && col[t] != i));
+    }
+  }
+  if (lane == 0) nnz_row[i] = distinct + 1;  // + diagonal (loop edges i-i carry no weight)
+}
+
+// Per row (sorted by k_sort_rows): the merged row with its diagonal, and the lumped mass.
 __global__ __launch_bounds__(256) void k_rows(int n, const int32_t* __restrict__ row_start,
-                                              Entry* __restrict__ ent,
+                                              const Entry* __restrict__ ent,
                                               const double* __restrict__ tri_area,
-                                              int32_t* __restrict__ nnz_row,
                                               const int32_t* __restrict__ indptr,
                                               int32_t* __restrict__ indices,
                                               double* __restrict__ vals,
@@ -652,23 +732,7 @@ __global__ __launch_bounds__(256) void k_rows(int n, const int32_t* __restrict__
   int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const int b = row_start[i], e = row_start[i + 1];
-  if (PASS == 0) {
-    for (int a = b + 1; a < e; ++a) {
-      const Entry x = ent[a];
-      int j = a;
-      while (j > b && ent_less(x, ent[j - 1])) {
-        ent[j] = ent[j - 1];
-        --j;
-      }
-      ent[j] = x;
-    }
-    int distinct = 0;
-    for (int a = b; a < e; ++a)
-      if (ent[a].col != i && (a == b || ent[a].col != ent[a - 1].col)) ++distinct;
-    nnz_row[i] = distinct + 1;  // + diagonal (loop edges i-i carry no weight)
-    return;
-  }
-  // PASS 1: merged off-diagonals in column order, diagonal inserted in place
+  // merged off-diagonals in column order, diagonal inserted in place
   double m = 0.0;
   for (int a = b; a < e; ++a) m += tri_area[ent[a].key >> 2] * 0.5;  // each face twice
   mass[i] = (m / 3.0) / 3.0;
@@ -847,9 +911,8 @@ int pyqsm_pc_laplacian(const double* xyz, int64_t n, int32_t k, double moll, int
                          d_ent, d_area);
       PQ_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(k_rows<0>, gn, blk, 0, c->stream, N, d_vcount, d_ent, d_area, d_nnzrow,
-                       static_cast<const int32_t*>(nullptr), static_cast<int32_t*>(nullptr),
-                       static_cast<double*>(nullptr), static_cast<double*>(nullptr));
+    hipLaunchKernelGGL(k_sort_rows, dim3(ceil_div(n, 4)), blk, 0, c->stream, N, d_vcount, d_ent,
+                       d_nnzrow);
     PQ_HIP(hipGetLastError());
     PQ_TRY(exclusive_scan_i32(c, d_nnzrow, n + 1));  // indptr
     int32_t nnz = 0;
@@ -859,8 +922,8 @@ int pyqsm_pc_laplacian(const double* xyz, int64_t n, int32_t k, double moll, int
     double* d_vals;
     PQ_TRY(c->arena.get(size_t(nnz) + 1, &d_indices));
     PQ_TRY(c->arena.get(size_t(nnz) + 1, &d_vals));
-    hipLaunchKernelGGL(k_rows<1>, gn, blk, 0, c->stream, N, d_vcount, d_ent, d_area, d_nnzrow,
-                       d_nnzrow, d_indices, d_vals, d_mass);
+    hipLaunchKernelGGL(k_rows, gn, blk, 0, c->stream, N, d_vcount, d_ent, d_area, d_nnzrow, d_indices,
+                       d_vals, d_mass);
     PQ_HIP(hipGetLastError());
     int32_t* h_indices = static_cast<int32_t*>(malloc((size_t(nnz) + 1) * 4));
     double* h_vals = static_cast<double*>(malloc((size_t(nnz) + 1) * 8));
