@@ -16,6 +16,9 @@ Secondary sections on the same JSON line:
               results all-gathered with RCCL (strong scaling, R fixed)
   knn         k = 20 neighbours on the same cloud
   roofline    dominant kernel of the primary path, HIP-event timed live
+  skeleton    the first --skel-iters Laplacian contractions of extract_skeleton on the
+              same cloud with the time split Laplacian / solve (N = 1 only: replicas)
+  ransac      1000 circle hypotheses x 50 k points (fit_shape_RANSAC's inner loop)
   cpu_baseline  scikit-learn DBSCAN (the reference's own call, fit.py:223) on the
               host cores of this box, rank 0, N = 1 only
 """
@@ -56,6 +59,11 @@ def parse():
     ap.add_argument("--no-rays", action="store_true")
     ap.add_argument("--no-knn", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--skel-iters", type=int, default=3,
+                    help="contraction steps of the skeleton section (config 3 runs 20: "
+                         "examples/config3_skeleton.py)")
+    ap.add_argument("--no-skeleton", action="store_true")
+    ap.add_argument("--no-ransac", action="store_true")
     return ap.parse_args()
 
 
@@ -263,6 +271,88 @@ def main():
                 "sample": f"{len(sub)} of the {R} rays x {T} triangles, brute-force "
                           "Moller-Trumbore in C/OpenMP (oracle/pyqsm_oracle.c); NOT Embree "
                           "(Open3D is not installable here)"}
+
+    # ------------------------------------------------------------- skeleton (config 3)
+    if not args.no_skeleton and world == 1:
+        from pyqsm_amd.geometry import skeletonize as skel
+        hip.prof_enable(True, dev)
+        hip.prof_reset(dev)
+        t0 = time.perf_counter()
+        _, total_shift, steps_done = skel.extract_skeleton(pts, max_iter=args.skel_iters,
+                                                           termination_ratio=0.0)
+        wall = time.perf_counter() - t0
+        prof = {k: hip.prof_get(k, dev) for k in ("lap_knn", "lap_fans", "lap_assemble",
+                                                  "lbc_amg_iter", "lbc_amg_build", "lbc_inner_iter",
+                                                  "lbc_outer_iter")}
+        hip.prof_enable(False, dev)
+        out["skeleton"] = {
+            "workload": f"{n}-point forest, first {len(steps_done)} of config 3's 20 contractions "
+                        "(extract_skeleton, TOML weights), wall incl. host loop and PCIe",
+            "wall_s": wall, "s_per_contraction": wall / max(len(steps_done), 1),
+            "laplacian_builds": prof["lap_knn"][1],
+            "laplacian_ms_per_build": sum(prof[k][0] for k in ("lap_knn", "lap_fans", "lap_assemble"))
+            / max(prof["lap_knn"][1], 1),
+            "solve_ms_total": prof["lbc_outer_iter"][0] + prof["lbc_amg_build"][0],
+            "outer_cg_steps": prof["lbc_outer_iter"][1],
+            "multigrid_cg_iterations": prof["lbc_amg_iter"][1],
+            "ms_per_multigrid_cg_iteration": prof["lbc_amg_iter"][0] / max(prof["lbc_amg_iter"][1], 1),
+            "jacobi_cg_iterations": prof["lbc_inner_iter"][1],
+            "mean_shift_m": float(np.linalg.norm(total_shift, axis=1).mean()), "dtype": "f64"}
+        if rank == 0 and not args.no_cpu:
+            # the reference's own solve (three SciPy spsolve calls, skeletonize.py:167-173)
+            # on a bounded sample: the first contraction of a 100 k-point forest
+            import oracle
+            ns = min(n, 100_000)
+            sub = synth.forest(ns, seed=0)
+            L, M = skel.point_cloud_laplacian(sub, mollify_factor=1e-6, n_neighbors=20, device=dev)
+            wl = np.full(ns, 3 * 1e3 * np.sqrt(np.mean(M.diagonal())))
+            wh = np.full(ns, 3.0)
+            t0 = time.perf_counter()
+            ref = oracle.least_squares_sparse(sub, L, wl, wh)
+            c = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            got = skel.least_squares_sparse(sub, L, wl, wh, device=dev)
+            g = time.perf_counter() - t0
+            out["skeleton"]["cpu_baseline"] = {
+                "value": ns / c / 1e6, "unit": "Mpoints/s per contraction solve", "cores": 1,
+                "kind": "reference",
+                "sample": f"first contraction solve of a {ns}-point forest by the reference's "
+                          "three scipy spsolve(COLAMD) calls (skeletonize.py:167-173) on the GPU-built "
+                          "Laplacian; same system on the GPU incl. PCIe",
+                "gpu_value": ns / g / 1e6,
+                "max_rel_diff": float(np.abs(got - ref).max() / np.abs(ref).max())}
+
+    # ------------------------------------------------------------- RANSAC circle fit
+    if not args.no_ransac and world == 1:
+        nr, H = 50_000, 1000
+        ring = synth.ring_cluster(nr, seed=3)
+        ring[:, 2] = 0.0                                   # fit.py:274-276: circle fit in z = 0
+        rng = np.random.default_rng(2)
+        triples = np.stack([rng.choice(nr, 3, replace=False) for _ in range(H)]).astype(np.int64)
+        hip.ransac(ring, triples, "circle", 0.04, dev)
+        reps = 5
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            res = hip.ransac(ring, triples, "circle", 0.04, dev)
+        dt = (time.perf_counter() - t0) / reps
+        out["ransac"] = {"workload": f"{H} circle hypotheses x {nr} points, threshold 0.04 "
+                                     "(qsm_generation.py:155), host buffers in, inliers out",
+                         "ms_per_fit": dt * 1e3, "value": H * nr / dt / 1e6,
+                         "unit": "Mpoint-hypothesis tests/s", "inliers": int(len(res[3])),
+                         "dtype": "f64"}
+        if rank == 0 and not args.no_cpu:
+            import oracle
+            hs = 100
+            t0 = time.perf_counter()
+            ref = oracle.ransac_fit(ring, triples[:hs], "circle", 0.04)
+            c = time.perf_counter() - t0
+            sub = hip.ransac(ring, triples[:hs], "circle", 0.04, dev)
+            out["ransac"]["cpu_baseline"] = {
+                "value": hs * nr / c / 1e6, "unit": "Mpoint-hypothesis tests/s", "cores": 1,
+                "kind": "port",
+                "sample": f"first {hs} of the {H} hypotheses, NumPy restatement of pyransac3d's "
+                          "Circle.fit loop (oracle.ransac_fit); same inliers as GPU: "
+                          f"{bool(np.array_equal(np.asarray(ref[3]), sub[3]))}"}
 
     # ------------------------------------------------------------- CPU baseline (primary)
     if rank == 0 and world == 1 and not args.no_cpu:
