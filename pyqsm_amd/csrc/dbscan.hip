@@ -179,13 +179,19 @@ __device__ __forceinline__ void st_parent(int* parent, int i, int v) {
   __hip_atomic_store(parent + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Parent pointers only ever decrease (a root is hooked under a smaller root), so
-// every pointer names an ancestor and halving a path is always safe.
+// Linking order. Hooking "larger index under smaller" on spatially sorted indices builds
+// chains (neighbours in space are neighbours in index), and every find then walks
+// hundreds of dependent loads. A bijective hash of the index as the priority is
+// randomised linking: expected depth O(log n). A root is hooked under a root of smaller
+// priority, so priorities strictly decrease towards the root: every pointer names an
+// ancestor, halving a path is always safe, and there are no cycles.
+__device__ __forceinline__ unsigned link_prio(int x) { return unsigned(x) * 0x9E3779B1u; }
+
 __device__ __forceinline__ int find_root(int* parent, int x) {
   int cur = ld_parent(parent, x);
   if (cur != x) {
     int prev = x, next;
-    while (cur > (next = ld_parent(parent, cur))) {
+    while (cur != (next = ld_parent(parent, cur))) {
       st_parent(parent, prev, next);
       prev = cur;
       cur = next;
@@ -197,15 +203,18 @@ __device__ __forceinline__ int find_root(int* parent, int x) {
 __device__ __forceinline__ void unite(int* parent, int a, int b) {
   int ra = find_root(parent, a), rb = find_root(parent, b);
   while (ra != rb) {
-    if (ra < rb) {
+    if (link_prio(ra) < link_prio(rb)) {
       int t = ra;
       ra = rb;
       rb = t;
     }
-    // hook the larger root under the smaller one
-    int old = atomicCAS(parent + ra, ra, rb);
+    // hook the root of larger priority under the other one
+    const int old = atomicCAS(parent + ra, ra, rb);
     if (old == ra) break;
-    ra = old;  // lost the race: ra already has a (smaller) parent, climb
+    // lost the race: ra has a parent now. Climb with loads, not with failing CAS
+    // operations (atomics on one address are served one at a time).
+    ra = find_root(parent, old);
+    rb = find_root(parent, rb);
   }
 }
 
@@ -214,77 +223,262 @@ __global__ __launch_bounds__(256) void k_init_parent(int n, int* __restrict__ pa
   if (p < n) parent[p] = p;
 }
 
-__global__ __launch_bounds__(256) void k_union(int n, Stencil st, const int32_t* __restrict__ start,
-                                               const int32_t* __restrict__ cell_of,
-                                               const double* __restrict__ sx,
-                                               const double* __restrict__ sy,
-                                               const double* __restrict__ sz, double r2,
-                                               const uint8_t* __restrict__ core, int* parent) {
+// ---- union phase over octant sub-cells -------------------------------------------------
+// Cells have an edge of eps (a hair more), so two points of the same octant sub-cell
+// (half a cell per axis) are at most 0.87 eps apart: the core points of a sub-cell are one
+// component without any test. What remains is to find, for every pair of sub-cells at
+// most two sub-cells apart per axis, ONE core-core pair within eps — and not even that
+// once the two are known to be in the same tree. The first version walked all ~850
+// candidates of every core point and chased a parent pointer for each of its ~40 core
+// neighbours (1.15 ms per million points, 91 % memory waits); this one looks at
+// 62 neighbour sub-cells per sub-cell, most of them empty or already joined.
+
+// The first point of every sub-cell run finds the run's first core point (the sub-cell's
+// representative), hangs the other core points of the run under it and lists it.
+__global__ __launch_bounds__(256) void k_sub_rep(int n, const int32_t* __restrict__ sub_of,
+                                                 const int32_t* __restrict__ sub_beg,
+                                                 const int32_t* __restrict__ sub_cnt,
+                                                 const uint8_t* __restrict__ core,
+                                                 const int32_t* __restrict__ order,
+                                                 int* __restrict__ parent,
+                                                 int32_t* __restrict__ sub_rep,
+                                                 int* __restrict__ run_min,
+                                                 int32_t* __restrict__ list,
+                                                 int32_t* __restrict__ list_cnt) {
   int p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= n || !core[p]) return;
-  const double x = sx[p], y = sy[p], z = sz[p];
-  const int c = cell_of[p];
-  // Most neighbours are already in p's tree after the first few unions. A plain
-  // (cached, possibly stale) read of parent[q] that equals a root p has been seen
-  // under proves "same tree" (trees only merge), so the coherent loads and the CAS
-  // are kept for the pairs that still look different.
-  const volatile int* vparent = parent;
-  int rp = find_root(parent, p);
-  FOR_STENCIL(c, st, start, q, {
-    // each unordered pair once
-    if (q < p && core[q] && sqdist(x, y, z, sx[q], sy[q], sz[q]) <= r2) {
-      if (vparent[q] != rp) {
-        unite(parent, p, q);
-        rp = find_root(parent, p);
-      }
+  int rep = -1;
+  if (p < n) {
+    const int sid = sub_of[p];
+    if (sub_beg[sid] == p) {
+      const int e = p + sub_cnt[sid];
+      int mn = 0x7FFFFFFF;
+      for (int q = p; q < e; ++q)
+        if (core[q]) {
+          if (rep < 0) rep = q;
+          parent[q] = rep;
+          mn = min(mn, order[q]);
+        }
+      sub_rep[sid] = rep;
+      if (rep >= 0) run_min[rep] = mn;  // smallest original index among the run's core points
     }
-  })
+  }
+  // block-aggregated append of the representatives: one atomic per block (atomics on a
+  // single address are served one at a time; one per wave cost 0.16 ms per million points)
+  __shared__ int wcount[4], wbase[4];
+  const unsigned long long b = __ballot(rep >= 0);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) wcount[w] = __popcll(b);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int tot = wcount[0] + wcount[1] + wcount[2] + wcount[3];
+    const int base = tot ? atomicAdd(list_cnt, tot) : 0;
+    wbase[0] = base;
+    wbase[1] = base + wcount[0];
+    wbase[2] = base + wcount[0] + wcount[1];
+    wbase[3] = base + wcount[0] + wcount[1] + wcount[2];
+  }
+  __syncthreads();
+  if (rep >= 0) list[wbase[w] + __popcll(b & ((1ull << lane) - 1ull))] = rep;
 }
 
-// (Measured alternatives for this kernel, MI355X, 1 M-point forest, per launch:
-//  per-lane walk above 1.15 ms; candidates staged through LDS like k_core_tiled with
-//  per-lane unite 1.4 ms; the same plus in-wave component labels so that one lane per
-//  local component talks to the global forest 1.3 ms. 91 % of the wave cycles are
-//  memory waits in the find/CAS chains themselves (profiles/r01_dbscan_sq_counters.csv),
-//  and SIMT serialisation of divergent unite() calls costs the tiled forms more than
-//  the cheaper traversal saves. The simple form stays.)
+// The 62 lexicographically positive (dz, dy, dx) offsets in [-2,2]^3 as (dx, dy, dz): the 13
+// of max-norm 1 first, then the 49 of max-norm 2.
+__constant__ signed char kSubOffsets[62][3] = {{1,0,0}, {-1,1,0}, {0,1,0}, {1,1,0}, {-1,-1,1}, {0,-1,1}, {1,-1,1}, {-1,0,1}, {0,0,1}, {1,0,1}, {-1,1,1}, {0,1,1}, {1,1,1}, {2,0,0}, {-2,1,0}, {2,1,0}, {-2,2,0}, {-1,2,0}, {0,2,0}, {1,2,0}, {2,2,0}, {-2,-2,1}, {-1,-2,1}, {0,-2,1}, {1,-2,1}, {2,-2,1}, {-2,-1,1}, {2,-1,1}, {-2,0,1}, {2,0,1}, {-2,1,1}, {2,1,1}, {-2,2,1}, {-1,2,1}, {0,2,1}, {1,2,1}, {2,2,1}, {-2,-2,2}, {-1,-2,2}, {0,-2,2}, {1,-2,2}, {2,-2,2}, {-2,-1,2}, {-1,-1,2}, {0,-1,2}, {1,-1,2}, {2,-1,2}, {-2,0,2}, {-1,0,2}, {0,0,2}, {1,0,2}, {2,0,2}, {-2,1,2}, {-1,1,2}, {0,1,2}, {1,1,2}, {2,1,2}, {-2,2,2}, {-1,2,2}, {0,2,2}, {1,2,2}, {2,2,2}};
 
-// root[p] for core points, then the smallest original index of each component.
-// A cluster of 50 k points would send 50 k atomicMin to one address (0.77 ms in
-// the first version): lanes of a wave that share a root fold their indices first,
-// and an atomic is issued only if it can still lower the stored minimum.
-__global__ __launch_bounds__(256) void k_flatten(int n, const uint8_t* __restrict__ core,
-                                                 int* __restrict__ parent,
-                                                 const int32_t* __restrict__ order,
+// Full path compression for the listed representatives (plain accesses: the kernel
+// boundary makes the unions of the previous launch visible, and any value another lane
+// writes meanwhile is an ancestor too).
+__global__ __launch_bounds__(256) void k_flatten_reps(const int32_t* __restrict__ list, int m,
+                                                      int* __restrict__ parent) {
+  int s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= m) return;
+  const int p = list[s];
+  int r = p;
+  for (int nx = parent[r]; nx != r; nx = parent[r]) r = nx;
+  parent[p] = r;
+}
+
+// Pass 1 of the union phase, without union-find: every sub-cell hangs itself under the
+// first neighbour it is connected to among the 62 lexicographically NEGATIVE offsets
+// (nearest first). Pointers only go to lexicographically smaller sub-cells, so there is
+// no cycle, every sub-cell writes its own pointer only (plain store, no atomics, no
+// chasing), and what remains after compression is a few trees per cluster — one per
+// sub-cell without a connected smaller neighbour. One wave per sub-cell as below.
+__global__ __launch_bounds__(256) void k_hook_sub(const int32_t* __restrict__ list, int m, int nx,
+                                                  int ny, const int32_t* __restrict__ start,
+                                                  const int32_t* __restrict__ cell_of,
+                                                  const int32_t* __restrict__ sub_of,
+                                                  const int32_t* __restrict__ sub_beg,
+                                                  const int32_t* __restrict__ sub_cnt,
+                                                  const int32_t* __restrict__ sub_rep,
+                                                  const double* __restrict__ sx,
+                                                  const double* __restrict__ sy,
+                                                  const double* __restrict__ sz, double r2,
+                                                  const uint8_t* __restrict__ core,
+                                                  int* __restrict__ parent) {
+  const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (s >= m) return;  // wave-uniform
+  const int k = threadIdx.x & 63;
+  const int p = list[s];
+  const int c1 = cell_of[p], sid1 = sub_of[p], o1 = sid1 & 7;
+  const int n1 = sub_beg[sid1] + sub_cnt[sid1] - p;  // p is the first core point of its run
+  const int cx = c1 % nx, cy = (c1 / nx) % ny, cz = c1 / (nx * ny);
+  int q0 = 0, n2 = 0, rep2 = -1;
+  if (k < 62) {
+    const int gx = 2 * (cx - 1) + (o1 & 1) - kSubOffsets[k][0],
+              gy = 2 * (cy - 1) + ((o1 >> 1) & 1) - kSubOffsets[k][1],
+              gz = 2 * (cz - 1) + ((o1 >> 2) & 1) - kSubOffsets[k][2];
+    const int c2 = (((gz >> 1) + 1) * ny + ((gy >> 1) + 1)) * nx + ((gx >> 1) + 1);
+    const int b2 = start[c2];
+    if (start[c2 + 1] != b2) {
+      const int sid2 = b2 * 8 + ((gx & 1) | ((gy & 1) << 1) | ((gz & 1) << 2));
+      n2 = sub_cnt[sid2];
+      if (n2 > 0) {
+        rep2 = sub_rep[sid2];
+        q0 = sub_beg[sid2];
+      }
+    }
+  }
+  unsigned long long todo = __ballot(rep2 >= 0);
+  while (todo) {
+    const int src = __ffsll(todo) - 1;
+    todo &= todo - 1;
+    const int qb = __shfl(q0, src, 64), nb = __shfl(n2, src, 64), rb = __shfl(rep2, src, 64);
+    const int pairs = n1 * nb;
+    bool found = false;
+    for (int base = 0; base < pairs && !found; base += 64) {
+      const int idx = base + k;
+      bool hit = false;
+      if (idx < pairs) {
+        const int a = p + idx / nb, q = qb + idx % nb;
+        hit = core[a] && core[q] && sqdist(sx[a], sy[a], sz[a], sx[q], sy[q], sz[q]) <= r2;
+      }
+      found = __ballot(hit) != 0;
+    }
+    if (found) {
+      if (k == 0) parent[p] = rb;
+      return;
+    }
+  }
+}
+
+// One WAVE per sub-cell with core points. Lane k < 62 looks at the k-th lexicographically
+// positive offset in [-2,2]^3 (every unordered pair of neighbouring sub-cells exactly once)
+// and decides whether that neighbour still has to be tested; then the wave takes the
+// neighbours that do one at a time and tests all |S1| x |S2| point pairs at once, 64 per
+// step. (A lane per pair of sub-cells running the pair loop itself was 3x slower: ~25
+// dependent iterations per lane, and a wave lasts as long as its slowest lane.)
+__global__ __launch_bounds__(256) void k_union_sub(const int32_t* __restrict__ list, int m, int k0,
+                                                   int k1, int nx, int ny,
+                                                   const int32_t* __restrict__ start,
+                                                   const int32_t* __restrict__ cell_of,
+                                                   const int32_t* __restrict__ sub_of,
+                                                   const int32_t* __restrict__ sub_beg,
+                                                   const int32_t* __restrict__ sub_cnt,
+                                                   const int32_t* __restrict__ sub_rep,
+                                                   const double* __restrict__ sx,
+                                                   const double* __restrict__ sy,
+                                                   const double* __restrict__ sz, double r2,
+                                                   const uint8_t* __restrict__ core, int* parent) {
+  const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (s >= m) return;  // wave-uniform
+  const int k = threadIdx.x & 63;
+  const int p = list[s];
+  const int c1 = cell_of[p], sid1 = sub_of[p], o1 = sid1 & 7;
+  const int n1 = sub_beg[sid1] + sub_cnt[sid1] - p;  // p is the first core point of its run
+  const int cx = c1 % nx, cy = (c1 / nx) % ny, cz = c1 / (nx * ny);
+  int q0 = 0, n2 = 0, rep2 = -1;
+  bool need = false;
+  const int r1 = find_root(parent, p);  // uniform: one chase for the whole wave
+  if (k >= k0 && k < k1) {
+    const int dx = kSubOffsets[k][0], dy = kSubOffsets[k][1], dz = kSubOffsets[k][2];
+    // half-cell coordinates (cell 1 is the first interior cell; borders are empty)
+    const int gx = 2 * (cx - 1) + (o1 & 1) + dx, gy = 2 * (cy - 1) + ((o1 >> 1) & 1) + dy,
+              gz = 2 * (cz - 1) + ((o1 >> 2) & 1) + dz;
+    const int c2 = (((gz >> 1) + 1) * ny + ((gy >> 1) + 1)) * nx + ((gx >> 1) + 1);
+    const int b2 = start[c2];
+    if (start[c2 + 1] != b2) {
+      const int sid2 = b2 * 8 + ((gx & 1) | ((gy & 1) << 1) | ((gz & 1) << 2));
+      n2 = sub_cnt[sid2];
+      if (n2 > 0) {
+        rep2 = sub_rep[sid2];
+        q0 = sub_beg[sid2];
+      }
+    }
+    if (rep2 >= 0) {
+      // A plain (cached, possibly stale) read names an ancestor; equal ancestors prove
+      // "same tree" (trees only merge). The coherent chase is for the rest.
+      const volatile int* vparent = parent;
+      const int a1 = vparent[p], a2 = vparent[rep2];
+      need = !(a1 == a2 || a2 == p || a1 == rep2 || a2 == r1);
+      if (need) need = find_root(parent, rep2) != r1;
+    }
+  }
+  unsigned long long todo = __ballot(need);
+  while (todo) {
+    const int src = __ffsll(todo) - 1;
+    todo &= todo - 1;
+    const int qb = __shfl(q0, src, 64), nb = __shfl(n2, src, 64), rb = __shfl(rep2, src, 64);
+    const int pairs = n1 * nb;
+    bool found = false;
+    for (int base = 0; base < pairs && !found; base += 64) {
+      const int idx = base + k;
+      bool hit = false;
+      if (idx < pairs) {
+        const int a = p + idx / nb, q = qb + idx % nb;
+        hit = core[a] && core[q] && sqdist(sx[a], sy[a], sz[a], sx[q], sy[q], sz[q]) <= r2;
+      }
+      found = __ballot(hit) != 0;
+    }
+    if (found && k == 0) unite(parent, p, rb);
+  }
+}
+
+// Smallest original core index of every component, folded from the per-run minima of
+// the representatives (k_sub_rep): 5x fewer values than points, wave-folded when the
+// wave's representatives share a root (the common case), and an atomic only if it can
+// still lower the stored minimum. (Folding all core points this way cost 0.23 ms per
+// million points: atomics and coherent loads on a handful of hot addresses.)
+__global__ __launch_bounds__(256) void k_rep_min(const int32_t* __restrict__ list, int m,
+                                                 const int* __restrict__ parent,
+                                                 const int* __restrict__ run_min,
                                                  int* __restrict__ min_orig) {
-  int p = blockIdx.x * 256 + threadIdx.x;
-  const bool active = p < n && core[p];
+  int s = blockIdx.x * 256 + threadIdx.x;
+  const bool active = s < m;
   int r = -1, v = 0x7FFFFFFF;
   if (active) {
-    r = p;
-    for (int nx = parent[r]; nx != r; nx = parent[r]) r = nx;  // plain loads: kernel boundary
-    parent[p] = r;  // benign: r is still an ancestor for concurrent readers
-    v = order[p];
+    const int p = list[s];
+    r = parent[p];  // k_flatten_reps ran: the root
+    v = run_min[p];
   }
-  // wave-level fold when every active lane has the same root (the common case)
   const unsigned long long act = __ballot(active);
   if (act == 0) return;
   const int lead = __ffsll(act) - 1;
   const int r0 = __shfl(r, lead, 64);
   if (__ballot(active && r != r0) == 0) {
-    int m = v;
+    int mn = v;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
-      const int o = __shfl_xor(m, off, 64);
-      m = o < m ? o : m;
+      const int o = __shfl_xor(mn, off, 64);
+      mn = o < mn ? o : mn;
     }
-    if ((threadIdx.x & 63) == lead && m < __hip_atomic_load(min_orig + r0, __ATOMIC_RELAXED,
-                                                            __HIP_MEMORY_SCOPE_AGENT))
-      atomicMin(min_orig + r0, m);
+    if ((threadIdx.x & 63) == lead && mn < __hip_atomic_load(min_orig + r0, __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_AGENT))
+      atomicMin(min_orig + r0, mn);
   } else if (active) {
     if (v < __hip_atomic_load(min_orig + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
       atomicMin(min_orig + r, v);
   }
+}
+
+// parent[p] = root for every core point (point -> representative -> root)
+__global__ __launch_bounds__(256) void k_flatten(int n, const uint8_t* __restrict__ core,
+                                                 int* __restrict__ parent) {
+  int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= n || !core[p]) return;
+  int r = p;
+  for (int nx = parent[r]; nx != r; nx = parent[r]) r = nx;
+  parent[p] = r;  // benign: r is still an ancestor for concurrent readers
 }
 
 __global__ __launch_bounds__(256) void k_mark_roots(int n, const uint8_t* __restrict__ core,
@@ -337,11 +531,13 @@ static int dbscan_device(Ctx* c, const double* xyz, int64_t n, double eps, int32
     return 0;
   }
   DevGrid g;
+  SubCells sub;
   {
     ProfScope ps(c, "dbscan_bin");
     // a hair wider than eps: rounding of the cell index can then never put two
     // points that are within eps of each other two cells apart
     PQ_TRY(build_grid(c, xyz, n, eps * (1.0 + 1.0 / 1048576.0), int64_t(1) << 28, &g));
+    PQ_TRY(subsort_octants(c, &g, n, &sub));
   }
   const int N = int(n);
   const dim3 grid(ceil_div(n, 256)), block(256);
@@ -354,6 +550,12 @@ static int dbscan_device(Ctx* c, const double* xyz, int64_t n, double eps, int32
   PQ_TRY(c->arena.get(size_t(n), &parent));
   PQ_TRY(c->arena.get(size_t(n), &min_orig));
   PQ_TRY(c->arena.get(size_t(n) + 1, &flag));
+  int32_t *sub_rep, *list, *list_cnt;
+  int* run_min;
+  PQ_TRY(c->arena.get(size_t(n), &run_min));
+  PQ_TRY(c->arena.get(size_t(n) * 8, &sub_rep));
+  PQ_TRY(c->arena.get(size_t(n), &list));
+  PQ_TRY(c->arena.get(1, &list_cnt));
   {
     ProfScope ps(c, "dbscan_core");
     hipLaunchKernelGGL(k_core_tiled, grid, block, 0, c->stream, N, st, int(g.ncell), g.start,
@@ -365,10 +567,28 @@ static int dbscan_device(Ctx* c, const double* xyz, int64_t n, double eps, int32
     hipLaunchKernelGGL(k_init_parent, grid, block, 0, c->stream, N, parent);
     PQ_HIP(hipMemsetAsync(min_orig, 0x7F, size_t(n) * 4, c->stream));  // 0x7F7F7F7F > any index
     PQ_HIP(hipMemsetAsync(flag, 0, (size_t(n) + 1) * 4, c->stream));
-    hipLaunchKernelGGL(k_union, grid, block, 0, c->stream, N, st, g.start, g.cell_of, g.sx, g.sy,
-                       g.sz, r2, core, parent);
+    PQ_HIP(hipMemsetAsync(list_cnt, 0, 4, c->stream));
+    hipLaunchKernelGGL(k_sub_rep, grid, block, 0, c->stream, N, sub.sub_of, sub.sub_beg, sub.sub_cnt,
+                       core, g.order, parent, sub_rep, run_min, list, list_cnt);
+    int32_t m = 0;
+    PQ_HIP(hipMemcpyAsync(&m, list_cnt, 4, hipMemcpyDeviceToHost, c->stream));
+    PQ_HIP(hipStreamSynchronize(c->stream));
+    if (m > 0) {
+      const dim3 gw(ceil_div(m, 4)), gl(ceil_div(m, 256));
+      hipLaunchKernelGGL(k_hook_sub, gw, block, 0, c->stream, list, m, g.nx, g.ny, g.start, g.cell_of,
+                         sub.sub_of, sub.sub_beg, sub.sub_cnt, sub_rep, g.sx, g.sy, g.sz, r2, core,
+                         parent);
+      hipLaunchKernelGGL(k_flatten_reps, gl, block, 0, c->stream, list, m, parent);
+      // what is left: joining the few trees per cluster. Almost every pair of neighbours
+      // now shows the same root through two plain loads.
+      hipLaunchKernelGGL(k_union_sub, gw, block, 0, c->stream, list, m, 0, 62, g.nx, g.ny, g.start,
+                         g.cell_of, sub.sub_of, sub.sub_beg, sub.sub_cnt, sub_rep, g.sx, g.sy, g.sz, r2,
+                         core, parent);
+      hipLaunchKernelGGL(k_flatten_reps, gl, block, 0, c->stream, list, m, parent);
+      hipLaunchKernelGGL(k_rep_min, gl, block, 0, c->stream, list, m, parent, run_min, min_orig);
+    }
     PQ_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_flatten, grid, block, 0, c->stream, N, core, parent, g.order, min_orig);
+    hipLaunchKernelGGL(k_flatten, grid, block, 0, c->stream, N, core, parent);
     hipLaunchKernelGGL(k_mark_roots, grid, block, 0, c->stream, N, core, parent, min_orig, flag);
     PQ_HIP(hipGetLastError());
     PQ_TRY(exclusive_scan_i32(c, flag, n + 1));

@@ -274,6 +274,102 @@ int build_grid(Ctx* c, const double* xyz, int64_t n, double min_cell, int64_t ma
 }
 
 
+// ---- octant sub-cells ------------------------------------------------------------------
+
+__device__ __forceinline__ int octant_bit(double v, double mn, double inv_cell, int ccoord) {
+  // position in half cells relative to the cell the point was binned into
+  const int h = int(floor((v - mn) * (2.0 * inv_cell))) - 2 * (ccoord - 1);
+  return h < 1 ? 0 : 1;
+}
+
+__global__ __launch_bounds__(256) void k_sub_count(int n, GridParams g,
+                                                   const int32_t* __restrict__ start,
+                                                   const int32_t* __restrict__ cell_of,
+                                                   const double* __restrict__ sx,
+                                                   const double* __restrict__ sy,
+                                                   const double* __restrict__ sz,
+                                                   int32_t* __restrict__ sub_cnt,
+                                                   int32_t* __restrict__ oct_rank) {
+  int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= n) return;
+  const int c = cell_of[p];
+  const int cx = c % g.nx, cy = (c / g.nx) % g.ny, cz = c / (g.nx * g.ny);
+  const int oct = octant_bit(sx[p], g.minx, g.inv_cell, cx) |
+                  (octant_bit(sy[p], g.miny, g.inv_cell, cy) << 1) |
+                  (octant_bit(sz[p], g.minz, g.inv_cell, cz) << 2);
+  const int rank = atomicAdd(&sub_cnt[size_t(start[c]) * 8 + oct], 1);
+  oct_rank[p] = (rank << 3) | oct;
+}
+
+// the first point of every cell turns its eight counts into run starts
+__global__ __launch_bounds__(256) void k_sub_prefix(int n, const int32_t* __restrict__ start,
+                                                    const int32_t* __restrict__ cell_of,
+                                                    const int32_t* __restrict__ sub_cnt,
+                                                    int32_t* __restrict__ sub_beg) {
+  int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= n || start[cell_of[p]] != p) return;
+  int run = p;
+#pragma unroll
+  for (int o = 0; o < 8; ++o) {
+    sub_beg[size_t(p) * 8 + o] = run;
+    run += sub_cnt[size_t(p) * 8 + o];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_sub_scatter(int n, const int32_t* __restrict__ start,
+                                                     const int32_t* __restrict__ cell_of,
+                                                     const int32_t* __restrict__ oct_rank,
+                                                     const int32_t* __restrict__ sub_beg,
+                                                     const int32_t* __restrict__ order,
+                                                     const double* __restrict__ sx,
+                                                     const double* __restrict__ sy,
+                                                     const double* __restrict__ sz,
+                                                     int32_t* __restrict__ order2,
+                                                     double* __restrict__ sx2,
+                                                     double* __restrict__ sy2,
+                                                     double* __restrict__ sz2,
+                                                     int32_t* __restrict__ sub_of) {
+  int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= n) return;
+  const int orc = oct_rank[p];
+  const int sid = start[cell_of[p]] * 8 + (orc & 7);
+  const int q = sub_beg[sid] + (orc >> 3);
+  order2[q] = order[p];
+  sx2[q] = sx[p];
+  sy2[q] = sy[p];
+  sz2[q] = sz[p];
+  sub_of[q] = sid;
+}
+
+int subsort_octants(Ctx* c, DevGrid* g, int64_t n, SubCells* sub) {
+  if (n > (int64_t(1) << 27)) return fail(PYQSM_ERANGE, "octant sub-cells: more than 2^27 points");
+  int32_t *oct_rank, *order2;
+  double *sx2, *sy2, *sz2;
+  PQ_TRY(c->arena.get(size_t(n) * 8, &sub->sub_cnt));
+  PQ_TRY(c->arena.get(size_t(n) * 8, &sub->sub_beg));
+  PQ_TRY(c->arena.get(size_t(n), &sub->sub_of));
+  PQ_TRY(c->arena.get(size_t(n), &oct_rank));
+  PQ_TRY(c->arena.get(size_t(n), &order2));
+  PQ_TRY(c->arena.get(size_t(n), &sx2));
+  PQ_TRY(c->arena.get(size_t(n), &sy2));
+  PQ_TRY(c->arena.get(size_t(n), &sz2));
+  PQ_HIP(hipMemsetAsync(sub->sub_cnt, 0, size_t(n) * 32, c->stream));
+  GridParams gp{g->minx, g->miny, g->minz, g->inv_cell, g->nx, g->ny, g->nz};
+  const dim3 grid(ceil_div(n, 256)), blk(256);
+  hipLaunchKernelGGL(k_sub_count, grid, blk, 0, c->stream, int(n), gp, g->start, g->cell_of, g->sx,
+                     g->sy, g->sz, sub->sub_cnt, oct_rank);
+  hipLaunchKernelGGL(k_sub_prefix, grid, blk, 0, c->stream, int(n), g->start, g->cell_of,
+                     sub->sub_cnt, sub->sub_beg);
+  hipLaunchKernelGGL(k_sub_scatter, grid, blk, 0, c->stream, int(n), g->start, g->cell_of, oct_rank,
+                     sub->sub_beg, g->order, g->sx, g->sy, g->sz, order2, sx2, sy2, sz2, sub->sub_of);
+  PQ_HIP(hipGetLastError());
+  g->order = order2;
+  g->sx = sx2;
+  g->sy = sy2;
+  g->sz = sz2;
+  return 0;
+}
+
 // ---- pyramid coarsening: a grid with cells `factor` times larger, without atomics ----
 // Coarse cell C gathers the factor^3 fine cells of its block; their point runs are
 // concatenated in (z, y, x) order, so a point's new position follows from its old one:

@@ -41,6 +41,21 @@ int cloud_bbox(Ctx* c, const double* xyz, int64_t n, double mn[3], double mx[3])
 int probe_occupancy(Ctx* c, const double* xyz, int64_t n, const double box[6], double cell,
                     double* cell_used, double* per_cell);
 
+// Octant sub-cells: the points of every cell re-sorted by the octant (half cell per axis)
+// they fall in. A sub-cell is identified by start[cell] * 8 + octant (first sorted
+// position of its cell, so ids are unique and need no compaction); its points are the run
+// [sub_beg[id], sub_beg[id] + sub_cnt[id]). sub_cnt is zero for empty octants of an
+// occupied cell; entries of unoccupied ids are never written and must not be read.
+struct SubCells {
+  int32_t* sub_cnt;  // [8 n]
+  int32_t* sub_beg;  // [8 n]
+  int32_t* sub_of;   // [n] sub-cell id of each sorted position
+};
+
+// Re-sorts g's point arrays in place (order, sx, sy, sz are replaced by new arena arrays;
+// start and cell_of stay valid: the permutation is within cells).
+int subsort_octants(Ctx* c, DevGrid* g, int64_t n, SubCells* sub);
+
 // A grid with cells `factor` times larger over the same points, derived from `fine`
 // by block sums and a deterministic scatter (no atomics, no second pass over xyz).
 int coarsen_grid(Ctx* c, const DevGrid& fine, int64_t n, int factor, DevGrid* coarse);
