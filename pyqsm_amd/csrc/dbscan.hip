@@ -127,13 +127,24 @@ struct TileLds {
 // LDS-broadcast fp64 loop 0.48 ms; the same with a rigorous fp32 pre-filter and the
 // chunk held in registers / broadcast by v_readlane 0.71 ms — issue-stall bound, see
 // profiles/r01_dbscan_sq_counters.csv. The simplest form won.)
+//
+// Only "at least min_pts" matters, so the wave stops as soon as (almost) all of its
+// points have seen enough neighbours: the runs are visited centre row first, and once
+// at most kStragglers lanes are still short they are put on a list for k_core_rest and
+// the wave leaves. In a dense cloud that is after 2-4 of the ~13 chunks; without the
+// straggler list one noise point would hold its whole wave to the end.
+static constexpr int kStragglers = 6;
+__constant__ int kRunOrder[9] = {4, 3, 5, 1, 7, 0, 2, 6, 8};  // centre, same-z rows, same-y rows, corners
+
 __global__ __launch_bounds__(256) void k_core_tiled(int n, Stencil st, int ncell,
                                                     const int32_t* __restrict__ start,
                                                     const int32_t* __restrict__ cell_of,
                                                     const double* __restrict__ sx,
                                                     const double* __restrict__ sy,
                                                     const double* __restrict__ sz, double r2,
-                                                    int min_pts, uint8_t* __restrict__ core) {
+                                                    int min_pts, uint8_t* __restrict__ core,
+                                                    int32_t* __restrict__ rest,
+                                                    int32_t* __restrict__ rest_cnt) {
   __shared__ TileLds L;
   // wave-uniform quantities are forced into SGPRs so that the loops below are scalar
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -144,13 +155,15 @@ __global__ __launch_bounds__(256) void k_core_tiled(int n, Stencil st, int ncell
   const double x = live ? sx[p] : 0.0, y = live ? sy[p] : 0.0, z = live ? sz[p] : 0.0;
   const Tile t = wave_tile(p0, n, st, ncell, start, cell_of);
   int cnt = 0;
+  bool deferred = false;
   if (t.total > kTileMax) {  // per-lane fallback
     if (live) {
       const int c = cell_of[p];
       FOR_STENCIL(c, st, start, q, { cnt += sqdist(x, y, z, sx[q], sy[q], sz[q]) <= r2; })
     }
   } else {
-    for (int r = 0; r < 9; ++r) {
+    for (int ri = 0; ri < 9 && !deferred; ++ri) {
+      const int r = kRunOrder[ri];
       for (int base = t.qb[r]; base < t.qe[r]; base += 64) {
         const int q = base + lane;
         const int m = t.qe[r] - base < 64 ? t.qe[r] - base : 64;
@@ -164,10 +177,58 @@ __global__ __launch_bounds__(256) void k_core_tiled(int n, Stencil st, int ncell
         for (int j = 0; j < m; ++j)
           cnt += sqdist(x, y, z, L.x[w][j], L.y[w][j], L.z[w][j]) <= r2;
         __builtin_amdgcn_wave_barrier();
+        const unsigned long long und = __ballot(live && cnt < min_pts);
+        if (__popcll(und) <= kStragglers && !(ri == 8 && base + 64 >= t.qe[r])) {
+          // the few lanes still short restart on their own in k_core_rest
+          if (und != 0) {
+            int slot = 0;
+            const int lead = __ffsll(und) - 1;
+            if (lane == lead) slot = atomicAdd(rest_cnt, __popcll(und));
+            slot = __shfl(slot, lead, 64);
+            if (live && cnt < min_pts) {
+              rest[slot + __popcll(und & ((1ull << lane) - 1ull))] = p;
+              cnt = -1;
+            }
+          }
+          deferred = true;
+          break;
+        }
       }
     }
   }
-  if (live) core[p] = cnt >= min_pts;
+  if (live && cnt >= 0) core[p] = cnt >= min_pts;
+}
+
+// The stragglers of k_core_tiled, one WAVE each: 64 candidates of the stencil per step,
+// stop at min_pts. (One lane each was 0.13 ms per million points: a noise point walks
+// ~850 candidates one dependent load at a time.)
+__global__ __launch_bounds__(256) void k_core_rest(const int32_t* __restrict__ rest,
+                                                   const int32_t* __restrict__ rest_cnt, Stencil st,
+                                                   const int32_t* __restrict__ start,
+                                                   const int32_t* __restrict__ cell_of,
+                                                   const double* __restrict__ sx,
+                                                   const double* __restrict__ sy,
+                                                   const double* __restrict__ sz, double r2,
+                                                   int min_pts, uint8_t* __restrict__ core) {
+  const int m = *rest_cnt;
+  const int lane = threadIdx.x & 63;
+  for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < m; i += gridDim.x * 4) {  // wave-uniform
+    const int p = rest[i];
+    const double x = sx[p], y = sy[p], z = sz[p];
+    const int c = cell_of[p];
+    int cnt = 0;
+    for (int dz = -1; dz <= 1 && cnt < min_pts; ++dz)
+      for (int dy = -1; dy <= 1 && cnt < min_pts; ++dy) {
+        const int row = c + dy * st.nx + dz * st.nxy;
+        const int qe = start[row + 2];
+        for (int base = start[row - 1]; base < qe && cnt < min_pts; base += 64) {
+          const int q = base + lane;
+          const bool hit = q < qe && sqdist(x, y, z, sx[q], sy[q], sz[q]) <= r2;
+          cnt += __popcll(__ballot(hit));
+        }
+      }
+    if (lane == 0) core[p] = cnt >= min_pts;
+  }
 }
 
 // ---- union-find --------------------------------------------------------------
@@ -443,6 +504,7 @@ __global__ __launch_bounds__(256) void k_rep_min(const int32_t* __restrict__ lis
                                                  const int* __restrict__ parent,
                                                  const int* __restrict__ run_min,
                                                  int* __restrict__ min_orig) {
+  __shared__ int wr[4], wm[4];
   int s = blockIdx.x * 256 + threadIdx.x;
   const bool active = s < m;
   int r = -1, v = 0x7FFFFFFF;
@@ -451,23 +513,39 @@ __global__ __launch_bounds__(256) void k_rep_min(const int32_t* __restrict__ lis
     r = parent[p];  // k_flatten_reps ran: the root
     v = run_min[p];
   }
+  const volatile int* vmin = min_orig;  // plain pre-check: a stale value only costs an atomic
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const unsigned long long act = __ballot(active);
-  if (act == 0) return;
-  const int lead = __ffsll(act) - 1;
+  const int lead = act ? __ffsll(act) - 1 : 0;
   const int r0 = __shfl(r, lead, 64);
-  if (__ballot(active && r != r0) == 0) {
-    int mn = v;
+  const bool uniform = act != 0 && __ballot(active && r != r0) == 0;
+  int mn = v;
+  if (uniform) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
       const int o = __shfl_xor(mn, off, 64);
       mn = o < mn ? o : mn;
     }
-    if ((threadIdx.x & 63) == lead && mn < __hip_atomic_load(min_orig + r0, __ATOMIC_RELAXED,
-                                                             __HIP_MEMORY_SCOPE_AGENT))
-      atomicMin(min_orig + r0, mn);
   } else if (active) {
-    if (v < __hip_atomic_load(min_orig + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-      atomicMin(min_orig + r, v);
+    if (v < vmin[r]) atomicMin(min_orig + r, v);
+  }
+  if (lane == 0) {
+    wr[w] = uniform ? r0 : -1;
+    wm[w] = mn;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    // waves of one block usually share the root: one atomic per block
+    for (int a = 0; a < 4; ++a) {
+      if (wr[a] < 0) continue;
+      int best = wm[a];
+      for (int b = a + 1; b < 4; ++b)
+        if (wr[b] == wr[a]) {
+          best = wm[b] < best ? wm[b] : best;
+          wr[b] = -1;
+        }
+      if (best < vmin[wr[a]]) atomicMin(min_orig + wr[a], best);
+    }
   }
 }
 
@@ -555,11 +633,16 @@ static int dbscan_device(Ctx* c, const double* xyz, int64_t n, double eps, int32
   PQ_TRY(c->arena.get(size_t(n), &run_min));
   PQ_TRY(c->arena.get(size_t(n) * 8, &sub_rep));
   PQ_TRY(c->arena.get(size_t(n), &list));
-  PQ_TRY(c->arena.get(1, &list_cnt));
+  PQ_TRY(c->arena.get(2, &list_cnt));
+  int32_t* rest;
+  PQ_TRY(c->arena.get(size_t(n), &rest));
   {
     ProfScope ps(c, "dbscan_core");
+    PQ_HIP(hipMemsetAsync(list_cnt + 1, 0, 4, c->stream));
     hipLaunchKernelGGL(k_core_tiled, grid, block, 0, c->stream, N, st, int(g.ncell), g.start,
-                       g.cell_of, g.sx, g.sy, g.sz, r2, min_pts, core);
+                       g.cell_of, g.sx, g.sy, g.sz, r2, min_pts, core, rest, list_cnt + 1);
+    hipLaunchKernelGGL(k_core_rest, dim3(std::min<int64_t>(8192, ceil_div(n, 64))), block, 0, c->stream,
+                       rest, list_cnt + 1, st, g.start, g.cell_of, g.sx, g.sy, g.sz, r2, min_pts, core);
     PQ_HIP(hipGetLastError());
   }
   {
