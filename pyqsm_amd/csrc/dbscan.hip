@@ -450,7 +450,6 @@ __global__ __launch_bounds__(256) void k_union_sub(const int32_t* __restrict__ l
   const int cx = c1 % nx, cy = (c1 / nx) % ny, cz = c1 / (nx * ny);
   int q0 = 0, n2 = 0, rep2 = -1;
   bool need = false;
-  const int r1 = find_root(parent, p);  // uniform: one chase for the whole wave
   if (k >= k0 && k < k1) {
     const int dx = kSubOffsets[k][0], dy = kSubOffsets[k][1], dz = kSubOffsets[k][2];
     // half-cell coordinates (cell 1 is the first interior cell; borders are empty)
@@ -471,8 +470,8 @@ __global__ __launch_bounds__(256) void k_union_sub(const int32_t* __restrict__ l
       // "same tree" (trees only merge). The coherent chase is for the rest.
       const volatile int* vparent = parent;
       const int a1 = vparent[p], a2 = vparent[rep2];
-      need = !(a1 == a2 || a2 == p || a1 == rep2 || a2 == r1);
-      if (need) need = find_root(parent, rep2) != r1;
+      need = !(a1 == a2 || a2 == p || a1 == rep2);
+      if (need) need = find_root(parent, rep2) != find_root(parent, p);
     }
   }
   unsigned long long todo = __ballot(need);
@@ -504,7 +503,6 @@ __global__ __launch_bounds__(256) void k_rep_min(const int32_t* __restrict__ lis
                                                  const int* __restrict__ parent,
                                                  const int* __restrict__ run_min,
                                                  int* __restrict__ min_orig) {
-  __shared__ int wr[4], wm[4];
   int s = blockIdx.x * 256 + threadIdx.x;
   const bool active = s < m;
   int r = -1, v = 0x7FFFFFFF;
@@ -514,38 +512,22 @@ __global__ __launch_bounds__(256) void k_rep_min(const int32_t* __restrict__ lis
     v = run_min[p];
   }
   const volatile int* vmin = min_orig;  // plain pre-check: a stale value only costs an atomic
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const unsigned long long act = __ballot(active);
-  const int lead = act ? __ffsll(act) - 1 : 0;
-  const int r0 = __shfl(r, lead, 64);
-  const bool uniform = act != 0 && __ballot(active && r != r0) == 0;
-  int mn = v;
-  if (uniform) {
+  const int lane = threadIdx.x & 63;
+  // a wave of representatives spans a few clusters (grid rows run across the whole scene):
+  // fold one root at a time
+  unsigned long long rem = __ballot(active);
+  while (rem) {
+    const int lead = __ffsll(rem) - 1;
+    const int r0 = __shfl(r, lead, 64);
+    const bool mine = active && r == r0;
+    int mn = mine ? v : 0x7FFFFFFF;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
       const int o = __shfl_xor(mn, off, 64);
       mn = o < mn ? o : mn;
     }
-  } else if (active) {
-    if (v < vmin[r]) atomicMin(min_orig + r, v);
-  }
-  if (lane == 0) {
-    wr[w] = uniform ? r0 : -1;
-    wm[w] = mn;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    // waves of one block usually share the root: one atomic per block
-    for (int a = 0; a < 4; ++a) {
-      if (wr[a] < 0) continue;
-      int best = wm[a];
-      for (int b = a + 1; b < 4; ++b)
-        if (wr[b] == wr[a]) {
-          best = wm[b] < best ? wm[b] : best;
-          wr[b] = -1;
-        }
-      if (best < vmin[wr[a]]) atomicMin(min_orig + wr[a], best);
-    }
+    if (lane == lead && mn < vmin[r0]) atomicMin(min_orig + r0, mn);
+    rem &= ~__ballot(mine);
   }
 }
 
