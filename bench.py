@@ -119,22 +119,33 @@ def main():
     barrier()
     elapsed = max_over_ranks(time.perf_counter() - t0)
     kernels = {}
-    for name in ("dbscan_bin", "dbscan_core", "dbscan_union", "dbscan_label", "dbscan_total"):
+    for name in ("dbscan_bin", "dbscan_core", "dbscan_union", "dbscan_label", "dbscan_total",
+                 "k_core_tiled", "k_hook_sub", "k_union_sub"):
         ms, cnt = hip.prof_get(name, dev)
         kernels[name] = {"avg_ms": ms / max(cnt, 1), "launches": cnt}
     hip.prof_enable(False, dev)
     labels = d_lab.download((n,), np.int64)
     n_clusters = int(labels.max() + 1)
     value = world * n * args.steps / elapsed / 1e6
-    dom = max(("dbscan_bin", "dbscan_core", "dbscan_union", "dbscan_label"),
-              key=lambda k: kernels[k]["avg_ms"])
+    # the three neighbourhood kernels are timed individually (HIP events on the library
+    # stream around the single launch); the phases above contain several small kernels each
+    dom = max(("k_core_tiled", "k_hook_sub", "k_union_sub"), key=lambda k: kernels[k]["avg_ms"])
     dom_ms = kernels[dom]["avg_ms"]
     achieved = DBSCAN_BYTES_PER_POINT * n / (dom_ms * 1e-3) / 1e9
+    traffic, traffic_note = None, "no PMC summary found under profiles/"
+    tpath = os.path.join(ROOT, "profiles", "r01_dbscan_traffic.json")
+    if os.path.exists(tpath):                        # written from the rocprofv3 --pmc passes
+        with open(tpath) as f:
+            tj = json.load(f)
+        if dom in tj.get("kernels", {}) and tj.get("points") == n:
+            traffic = tj["kernels"][dom]["hbm_bytes_per_launch"]
+            traffic_note = tj.get("note", "")
     roofline = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "avg_launch_ms": dom_ms,
                 "note": "algorithmic bytes = 341 B/point (SURVEY.md §8d) x points per launch; "
-                        "the neighbour kernels are FP64-VALU/latency bound, not HBM bound"}
+                        "the neighbour kernels are FP64-VALU/latency bound, not HBM bound. "
+                        "traffic: " + traffic_note}
 
     out = {
         "metric": "Mpoints/s DBSCAN (1M-pt synthetic forest, eps=0.1, min_neighbors=10)",

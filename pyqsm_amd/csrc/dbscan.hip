@@ -134,7 +134,8 @@ struct TileLds {
 // the wave leaves. In a dense cloud that is after 2-4 of the ~13 chunks; without the
 // straggler list one noise point would hold its whole wave to the end.
 static constexpr int kStragglers = 6;
-__constant__ int kRunOrder[9] = {4, 3, 5, 1, 7, 0, 2, 6, 8};  // centre, same-z rows, same-y rows, corners
+// centre, same-z rows, same-y rows, corners (compile-time: the run bounds stay in SGPRs)
+__device__ constexpr int kRunOrder[9] = {4, 3, 5, 1, 7, 0, 2, 6, 8};
 
 __global__ __launch_bounds__(256) void k_core_tiled(int n, Stencil st, int ncell,
                                                     const int32_t* __restrict__ start,
@@ -162,9 +163,10 @@ __global__ __launch_bounds__(256) void k_core_tiled(int n, Stencil st, int ncell
       FOR_STENCIL(c, st, start, q, { cnt += sqdist(x, y, z, sx[q], sy[q], sz[q]) <= r2; })
     }
   } else {
-    for (int ri = 0; ri < 9 && !deferred; ++ri) {
+#pragma unroll
+    for (int ri = 0; ri < 9; ++ri) {
       const int r = kRunOrder[ri];
-      for (int base = t.qb[r]; base < t.qe[r]; base += 64) {
+      for (int base = t.qb[r]; base < t.qe[r] && !deferred; base += 64) {
         const int q = base + lane;
         const int m = t.qe[r] - base < 64 ? t.qe[r] - base : 64;
         if (q < t.qe[r]) {
@@ -621,8 +623,11 @@ static int dbscan_device(Ctx* c, const double* xyz, int64_t n, double eps, int32
   {
     ProfScope ps(c, "dbscan_core");
     PQ_HIP(hipMemsetAsync(list_cnt + 1, 0, 4, c->stream));
-    hipLaunchKernelGGL(k_core_tiled, grid, block, 0, c->stream, N, st, int(g.ncell), g.start,
-                       g.cell_of, g.sx, g.sy, g.sz, r2, min_pts, core, rest, list_cnt + 1);
+    {
+      ProfScope pk(c, "k_core_tiled");
+      hipLaunchKernelGGL(k_core_tiled, grid, block, 0, c->stream, N, st, int(g.ncell), g.start,
+                         g.cell_of, g.sx, g.sy, g.sz, r2, min_pts, core, rest, list_cnt + 1);
+    }
     hipLaunchKernelGGL(k_core_rest, dim3(std::min<int64_t>(8192, ceil_div(n, 64))), block, 0, c->stream,
                        rest, list_cnt + 1, st, g.start, g.cell_of, g.sx, g.sy, g.sz, r2, min_pts, core);
     PQ_HIP(hipGetLastError());
@@ -640,15 +645,21 @@ static int dbscan_device(Ctx* c, const double* xyz, int64_t n, double eps, int32
     PQ_HIP(hipStreamSynchronize(c->stream));
     if (m > 0) {
       const dim3 gw(ceil_div(m, 4)), gl(ceil_div(m, 256));
-      hipLaunchKernelGGL(k_hook_sub, gw, block, 0, c->stream, list, m, g.nx, g.ny, g.start, g.cell_of,
-                         sub.sub_of, sub.sub_beg, sub.sub_cnt, sub_rep, g.sx, g.sy, g.sz, r2, core,
-                         parent);
+      {
+        ProfScope pk(c, "k_hook_sub");
+        hipLaunchKernelGGL(k_hook_sub, gw, block, 0, c->stream, list, m, g.nx, g.ny, g.start, g.cell_of,
+                           sub.sub_of, sub.sub_beg, sub.sub_cnt, sub_rep, g.sx, g.sy, g.sz, r2, core,
+                           parent);
+      }
       hipLaunchKernelGGL(k_flatten_reps, gl, block, 0, c->stream, list, m, parent);
       // what is left: joining the few trees per cluster. Almost every pair of neighbours
       // now shows the same root through two plain loads.
-      hipLaunchKernelGGL(k_union_sub, gw, block, 0, c->stream, list, m, 0, 62, g.nx, g.ny, g.start,
-                         g.cell_of, sub.sub_of, sub.sub_beg, sub.sub_cnt, sub_rep, g.sx, g.sy, g.sz, r2,
-                         core, parent);
+      {
+        ProfScope pk(c, "k_union_sub");
+        hipLaunchKernelGGL(k_union_sub, gw, block, 0, c->stream, list, m, 0, 62, g.nx, g.ny, g.start,
+                           g.cell_of, sub.sub_of, sub.sub_beg, sub.sub_cnt, sub_rep, g.sx, g.sy, g.sz, r2,
+                           core, parent);
+      }
       hipLaunchKernelGGL(k_flatten_reps, gl, block, 0, c->stream, list, m, parent);
       hipLaunchKernelGGL(k_rep_min, gl, block, 0, c->stream, list, m, parent, run_min, min_orig);
     }
