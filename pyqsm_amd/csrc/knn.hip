@@ -14,6 +14,12 @@
 // kMaxRing shells (isolated outliers) are retried on a 4x coarser grid, and so
 // on, until the grid is small enough for the rings to cover it entirely.
 //
+// (Measured alternative for level 0, MI355X, 1 M points, k = 20: a wave-tiled search like
+// dbscan.hip's k_core_tiled — 64 consecutive queries, candidates broadcast from LDS, the K
+// best per lane sorted in registers, branch-free insertion — took 9.0 ms against 5.1 ms for
+// the per-lane walk below: almost every candidate beats SOME lane's current worst, so the
+// ~300-instruction insertion step runs for nearly all of the tile's superset of candidates.)
+//
 // Distances are squared, fp64, ((dx*dx)+dy*dy)+dz*dz with separately rounded
 // products — the accumulation order of scipy's cKDTree — and candidates are
 // ordered by (d2, original index).
