@@ -63,3 +63,56 @@ def test_non_finite_is_an_error(gpu):
     P[3, 1] = np.nan
     with pytest.raises(PyQSMHipError):
         hip.dbscan(P, 0.1, 3, device=gpu)
+
+
+@pytest.mark.parametrize("seed,n,eps", [(5, 30_000, 0.02), (6, 30_000, 0.026), (7, 5_000, 0.05)])
+def test_single_link_components_min_pts_1(gpu, seed, n, eps):
+    """min_pts = 1: every point is core, clusters are the connected components of the eps
+    graph — around the percolation threshold they come in all sizes and shapes."""
+    rng = np.random.default_rng(seed)
+    Q = rng.uniform(0, 1, (n, 3)).astype(np.float32).astype(np.float64)
+    lab, core = _check(Q, eps, 1, gpu)
+    assert core.all() and lab.min() == 0 and lab.max() > 50
+
+
+def test_lattice_at_exactly_eps(gpu):
+    """Exactly representable spacing: d2 == eps^2 joins (inclusive compare), one ulp more does
+    not; neighbours then sit exactly one cell / two sub-cells apart."""
+    g = np.stack(np.meshgrid(*[np.arange(12.0)] * 3, indexing="ij"), -1).reshape(-1, 3) * 0.125
+    lab, core = _check(g, 0.125, 7, gpu)          # interior points have 6 neighbours + themselves
+    assert lab.max() == 0
+    lab, core = _check(g, np.nextafter(0.125, 0), 2, gpu)
+    assert not core.any() and (lab == -1).all()
+
+
+def test_two_blobs_joined_by_one_core_pair(gpu):
+    rng = np.random.default_rng(8)
+    a = rng.normal(0, 0.01, (300, 3))
+    b = rng.normal(0, 0.01, (300, 3)) + [0.5, 0, 0]
+    # a chain of core points between them, neighbours exactly eps = 0.0625 apart; every chain
+    # point is made core by two satellites
+    chain = np.array([[0.0625 * i, 0.3, 0.0] for i in range(9)])
+    sat = np.concatenate([chain + [0, 0.01, 0], chain + [0, -0.01, 0]])
+    hook_a = np.array([[0.0, 0.3 - 0.0625 * i, 0.0] for i in range(1, 5)])
+    hook_b = np.array([[0.5, 0.3 - 0.0625 * i, 0.0] for i in range(1, 5)])
+    hooks = np.concatenate([hook_a, hook_b])
+    hsat = np.concatenate([hooks + [0.01, 0, 0], hooks + [-0.01, 0, 0]])
+    P = np.concatenate([a, b, chain, sat, hooks, hsat]).astype(np.float32).astype(np.float64)
+    lab, core = _check(P, 0.0625, 3, gpu)
+    assert lab[0] == lab[300]                       # the blobs are one cluster through the chain
+    Q = np.delete(P, [604, 609 + 4, 618 + 4], axis=0)   # cut the chain (link 4 and its satellites)
+    lab, _ = _check(Q, 0.0625, 3, gpu)
+    assert lab[0] != lab[300]
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 257])
+def test_sizes_around_a_wave(gpu, n):
+    rng = np.random.default_rng(n)
+    _check(rng.normal(0, 0.05, (n, 3)), 0.03, 3, gpu)
+
+
+def test_planar_and_single_cell(gpu):
+    rng = np.random.default_rng(9)
+    P = np.concatenate([rng.uniform(0, 1, (8000, 2)), np.zeros((8000, 1))], 1)
+    _check(P, 0.02, 4, gpu)                         # z extent zero
+    _check(rng.uniform(0, 0.01, (500, 3)), 1.0, 5, gpu)   # eps far above the extent: one cell
