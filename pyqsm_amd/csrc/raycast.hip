@@ -268,16 +268,20 @@ __global__ void k_dir_records(const TriRec* __restrict__ tri, int64_t T,
   out[i] = DirRec{t.v0x, t.v0y, t.v0z, px[0], py[0], pz[0], det[0], 0.f};
 }
 
-// flag = 1 unless every ray has bitwise the direction of ray 0
+// flag bit 0: some ray's direction differs (bitwise) from ray 0's; bit 1: some origin does
 __global__ void k_check_uniform(const float* __restrict__ rays, int64_t R,
                                 int* __restrict__ flag) {
   const unsigned int* u = reinterpret_cast<const unsigned int*>(rays);
-  const unsigned int d0 = u[3], d1 = u[4], d2 = u[5];
-  bool diff = false;
+  const unsigned int o0 = u[0], o1 = u[1], o2 = u[2], d0 = u[3], d1 = u[4], d2 = u[5];
+  bool ddiff = false, odiff = false;
   for (int64_t r = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; r < R;
-       r += int64_t(gridDim.x) * blockDim.x)
-    diff |= u[6 * r + 3] != d0 || u[6 * r + 4] != d1 || u[6 * r + 5] != d2;
-  if (__builtin_amdgcn_ballot_w64(diff) != 0 && (threadIdx.x & 63) == 0) *flag = 1;
+       r += int64_t(gridDim.x) * blockDim.x) {
+    ddiff |= u[6 * r + 3] != d0 || u[6 * r + 4] != d1 || u[6 * r + 5] != d2;
+    odiff |= u[6 * r] != o0 || u[6 * r + 1] != o1 || u[6 * r + 2] != o2;
+  }
+  const int bits = (__builtin_amdgcn_ballot_w64(ddiff) != 0 ? 1 : 0) |
+                   (__builtin_amdgcn_ballot_w64(odiff) != 0 ? 2 : 0);
+  if (bits && (threadIdx.x & 63) == 0) atomicOr(flag, bits);
 }
 
 template <int NP>
@@ -598,6 +602,246 @@ __global__ __launch_bounds__(256) void k_cast_parallel_culled(
   }
 }
 
+// ---- common-origin batches (the pinhole camera of cast_rays) ----------------------------
+// All rays start at one point O and look into one half space (every direction within
+// ~75 degrees of their mean n). Central projection from O onto the plane n.x = 1 maps a ray
+// to a point (u, v) and a triangle in front of O to a triangle, so the rectangle culling of
+// the parallel case carries over with image coordinates in place of plane coordinates.
+// Triangles that reach behind (or too close to) the eye plane get an unbounded rectangle:
+// they are tested by every wave. The per-test arithmetic is the general kernel's, and the
+// closest hit is decided by (t, original id): results are bit-identical to k_cast_rays.
+struct Camera {
+  double ox, oy, oz, ax, ay, az, bx, by, bz, nx, ny, nz;
+};
+
+// sum of the unit directions (3 doubles) -> mean viewing direction
+__global__ __launch_bounds__(256) void k_dir_sum(const float* __restrict__ rays, int64_t R,
+                                                 double* __restrict__ sum) {
+  double sx = 0.0, sy = 0.0, sz = 0.0;
+  for (int64_t r = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; r < R;
+       r += int64_t(gridDim.x) * blockDim.x) {
+    const double x = rays[6 * r + 3], y = rays[6 * r + 4], z = rays[6 * r + 5];
+    const double n = sqrt(x * x + y * y + z * z);
+    if (n > 0.0) {
+      sx += x / n;
+      sy += y / n;
+      sz += z / n;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    sx += __shfl_down(sx, off, 64);
+    sy += __shfl_down(sy, off, 64);
+    sz += __shfl_down(sz, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(sum, sx);
+    atomicAdd(sum + 1, sy);
+    atomicAdd(sum + 2, sz);
+  }
+}
+
+// image coordinates of every ray (as [R][3] points for the bounding-box pass); flags rays
+// that look too far sideways for the projection (or have a zero / non-finite direction)
+__global__ __launch_bounds__(256) void k_ray_image(const float* __restrict__ rays, int64_t R,
+                                                   Camera cam, double min_cos,
+                                                   double* __restrict__ img,
+                                                   int* __restrict__ bad) {
+  int64_t r = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+  if (r >= R) return;
+  const double x = rays[6 * r + 3], y = rays[6 * r + 4], z = rays[6 * r + 5];
+  const double len = sqrt(x * x + y * y + z * z);
+  const double w = x * cam.nx + y * cam.ny + z * cam.nz;
+  double u = 0.0, v = 0.0;
+  if (!(w > min_cos * len) || !(len > 0.0) || !(len < 1e300)) {
+    *bad = 1;
+  } else {
+    u = (x * cam.ax + y * cam.ay + z * cam.az) / w;
+    v = (x * cam.bx + y * cam.by + z * cam.bz) / w;
+  }
+  img[3 * r] = u;
+  img[3 * r + 1] = v;
+  img[3 * r + 2] = 0.0;
+}
+
+// per triangle: projected centroid (clamped into the rays' image box, for sorting) and
+// projected bounding rectangle (unbounded when a vertex is not safely in front of O)
+__global__ __launch_bounds__(256) void k_tri_image(const TriRec* __restrict__ tri, int64_t T,
+                                                   Camera cam, double u_lo, double u_hi,
+                                                   double v_lo, double v_hi,
+                                                   double* __restrict__ cen /*[T][3]*/,
+                                                   float4* __restrict__ rect /*[T]*/) {
+  int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+  if (i >= T) return;
+  const Tri t = load_tri(tri, int(i));
+  const double px[3] = {double(t.v0x), double(t.v0x) + double(t.e1x), double(t.v0x) + double(t.e2x)};
+  const double py[3] = {double(t.v0y), double(t.v0y) + double(t.e1y), double(t.v0y) + double(t.e2y)};
+  const double pz[3] = {double(t.v0z), double(t.v0z) + double(t.e1z), double(t.v0z) + double(t.e2z)};
+  double u0 = 1e300, u1 = -1e300, v0 = 1e300, v1 = -1e300, uc = 0.0, vc = 0.0;
+  bool front = true;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double rx = px[k] - cam.ox, ry = py[k] - cam.oy, rz = pz[k] - cam.oz;
+    const double x = rx * cam.ax + ry * cam.ay + rz * cam.az;
+    const double y = rx * cam.bx + ry * cam.by + rz * cam.bz;
+    const double w = rx * cam.nx + ry * cam.ny + rz * cam.nz;
+    if (!(w > 1e-6 * (fabs(x) + fabs(y)) && w > 0.0)) {
+      front = false;
+    } else {
+      const double u = x / w, v = y / w;
+      u0 = u < u0 ? u : u0;
+      u1 = u > u1 ? u : u1;
+      v0 = v < v0 ? v : v0;
+      v1 = v > v1 ? v : v1;
+      uc += u;
+      vc += v;
+    }
+  }
+  if (front) {
+    uc /= 3.0;
+    vc /= 3.0;
+    rect[i] = make_float4(__double2float_rd(u0), __double2float_ru(u1), __double2float_rd(v0),
+                          __double2float_ru(v1));
+  } else {
+    uc = vc = 0.0;
+    rect[i] = make_float4(-__builtin_inff(), __builtin_inff(), -__builtin_inff(), __builtin_inff());
+  }
+  cen[3 * i] = uc < u_lo ? u_lo : (uc > u_hi ? u_hi : uc);
+  cen[3 * i + 1] = vc < v_lo ? v_lo : (vc > v_hi ? v_hi : vc);
+  cen[3 * i + 2] = 0.0;
+}
+
+// sorted original ids and one grown rectangle per cluster
+__global__ __launch_bounds__(256) void k_clusters_image(int T, const int32_t* __restrict__ order,
+                                                        const float4* __restrict__ rect,
+                                                        float margin, int32_t* __restrict__ sid,
+                                                        float4* __restrict__ crect) {
+  const int cl = blockIdx.x * 256 + threadIdx.x;
+  const int nclus = (T + kCluster - 1) / kCluster;
+  if (cl >= nclus) return;
+  float u0 = __builtin_inff(), u1 = -__builtin_inff(), v0 = __builtin_inff(), v1 = -__builtin_inff();
+  for (int s = cl * kCluster; s < (cl + 1) * kCluster && s < T; ++s) {
+    const int o = order[s];
+    sid[s] = o;
+    const float4 q = rect[o];
+    u0 = fminf(u0, q.x);
+    u1 = fmaxf(u1, q.y);
+    v0 = fminf(v0, q.z);
+    v1 = fmaxf(v1, q.w);
+  }
+  crect[cl] = make_float4(u0 - margin, u1 + margin, v0 - margin, v1 + margin);
+}
+
+template <int NP>
+__global__ __launch_bounds__(256) void k_cast_pinhole_culled(
+    const TriRec* __restrict__ tri, const int32_t* __restrict__ sid,
+    const float4* __restrict__ crect, const float4* __restrict__ srect, int T, Camera cam,
+    const float* __restrict__ rays, int64_t R, float* __restrict__ t_hit,
+    uint32_t* __restrict__ prim_id, float* __restrict__ uv) {
+  constexpr int RPL = 2 * NP;
+  // a wave owns 64*RPL CONSECUTIVE rays (a piece of an image row): a small image rectangle
+  const int64_t block_base =
+      int64_t(blockIdx.x) * (256 * RPL) + int64_t(threadIdx.x >> 6) * (64 * RPL) + (threadIdx.x & 63);
+  RayPair rp[NP];
+  float best_t[RPL];
+  uint32_t best_p[RPL];
+  double umin = 1e300, umax = -1e300, vmin = 1e300, vmax = -1e300;
+#pragma unroll
+  for (int k = 0; k < RPL; ++k) {
+    int64_t r = block_base + int64_t(k) * 64;
+    float o0 = 0.f, o1 = 0.f, o2 = 0.f, d0 = 0.f, d1 = 0.f, d2 = 0.f;
+    if (r < R) {
+      const float* p = rays + 6 * r;
+      o0 = p[0]; o1 = p[1]; o2 = p[2]; d0 = p[3]; d1 = p[4]; d2 = p[5];
+      const double w = double(d0) * cam.nx + double(d1) * cam.ny + double(d2) * cam.nz;
+      const double u = (double(d0) * cam.ax + double(d1) * cam.ay + double(d2) * cam.az) / w;
+      const double v = (double(d0) * cam.bx + double(d1) * cam.by + double(d2) * cam.bz) / w;
+      umin = u < umin ? u : umin;
+      umax = u > umax ? u : umax;
+      vmin = v < vmin ? v : vmin;
+      vmax = v > vmax ? v : vmax;
+    }
+    rp[k >> 1].ox[k & 1] = o0; rp[k >> 1].oy[k & 1] = o1; rp[k >> 1].oz[k & 1] = o2;
+    rp[k >> 1].dx[k & 1] = d0; rp[k >> 1].dy[k & 1] = d1; rp[k >> 1].dz[k & 1] = d2;
+    best_t[k] = __builtin_inff();
+    best_p[k] = PYQSM_MISS_PRIM;
+  }
+  const float ru0 = wave_min_f(__double2float_rd(umin)), ru1 = wave_max_f(__double2float_ru(umax));
+  const float rv0 = wave_min_f(__double2float_rd(vmin)), rv1 = wave_max_f(__double2float_ru(vmax));
+
+  auto sweep = [&](const Tri t, const uint32_t id) {
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      f2 px, py, pz, det, tvx, tvy, tvz, U;
+      mt_front(rp[q], t, px, py, pz, det, tvx, tvy, tvz, U);
+      const f2 key = alive_key(det, U);
+      bool alive = u_alive(key[0], det[0]) || u_alive(key[1], det[1]);
+      if (__builtin_amdgcn_ballot_w64(alive) != 0) {
+        f2 V, Tn;
+        mt_back(rp[q], t, tvx, tvy, tvz, V, Tn);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          if (is_hit(det[h], U[h], V[h], Tn[h])) {
+            float tt = Tn[h] / det[h];
+            // same winner as the in-order sweep: smallest t, then smallest triangle id
+            if (tt < best_t[2 * q + h] || (tt == best_t[2 * q + h] && id < best_p[2 * q + h])) {
+              best_t[2 * q + h] = tt;
+              best_p[2 * q + h] = id;
+            }
+          }
+        }
+      }
+    }
+  };
+  const int nclus = (T + kCluster - 1) / kCluster;
+  const int nsup = (nclus + kSuper - 1) / kSuper;
+  const float su0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ru0)));
+  const float su1 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ru1)));
+  const float sv0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, rv0)));
+  const float sv1 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, rv1)));
+  float4 nxt = srect[0];
+  for (int sc = 0; sc < nsup; ++sc) {
+    const float4 sr = nxt;
+    nxt = srect[sc + 1 < nsup ? sc + 1 : sc];
+    if (su1 < sr.x || su0 > sr.y || sv1 < sr.z || sv0 > sr.w) continue;
+    const int c1 = (sc + 1) * kSuper < nclus ? (sc + 1) * kSuper : nclus;
+    for (int cl = sc * kSuper; cl < c1; ++cl) {
+      const float4 cr = crect[cl];  // wave-uniform address
+      if (su1 < cr.x || su0 > cr.y || sv1 < cr.z || sv0 > cr.w) continue;
+      const int s1 = (cl + 1) * kCluster < T ? (cl + 1) * kCluster : T;
+      for (int s = cl * kCluster; s < s1; ++s) {
+        const int id = __builtin_amdgcn_readfirstlane(sid[s]);
+        sweep(load_tri(tri, id), uint32_t(id));
+      }
+    }
+  }
+
+#pragma unroll
+  for (int k = 0; k < RPL; ++k) {
+    int64_t r = block_base + int64_t(k) * 64;
+    if (r >= R) continue;
+    t_hit[r] = best_t[k];
+    prim_id[r] = best_p[k];
+    if (uv) {
+      float u = 0.f, v = 0.f;
+      if (best_p[k] != PYQSM_MISS_PRIM) {
+        const Tri t = load_tri(tri, int(best_p[k]));
+        RayPair one;
+        const int q = k >> 1, h = k & 1;
+        one.ox = splat(rp[q].ox[h]); one.oy = splat(rp[q].oy[h]); one.oz = splat(rp[q].oz[h]);
+        one.dx = splat(rp[q].dx[h]); one.dy = splat(rp[q].dy[h]); one.dz = splat(rp[q].dz[h]);
+        f2 px, py, pz, det, tvx, tvy, tvz, U, V, Tn;
+        mt_front(one, t, px, py, pz, det, tvx, tvy, tvz, U);
+        mt_back(one, t, tvx, tvy, tvz, V, Tn);
+        u = U[0] / det[0];
+        v = V[0] / det[0];
+      }
+      uv[2 * r] = u;
+      uv[2 * r + 1] = v;
+    }
+  }
+}
+
 // Crossing counts and (optionally) hit records: one ray per lane, all triangles.
 // mode 0: counts only. mode 1: write records at offsets[r] + running index.
 template <int MODE>
@@ -700,9 +944,11 @@ static int launch_cast(Ctx* c, const TriRec* tri, int64_t T, const float* rays, 
   hipLaunchKernelGGL(k_check_uniform, dim3(std::min<int64_t>(ceil_div(R, 256), 2048)), dim3(256), 0,
                      c->stream, rays, R, d_flag);
   PQ_HIP(hipGetLastError());
-  int varied = 0;
-  PQ_HIP(hipMemcpyAsync(&varied, d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  int uni_bits = 0;
+  PQ_HIP(hipMemcpyAsync(&uni_bits, d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   PQ_HIP(hipStreamSynchronize(c->stream));
+  const int varied = uni_bits & 1;          // directions differ
+  const bool one_origin = !(uni_bits & 2);  // every ray starts at ray 0's origin
   // Rays per lane: 8 when there are enough rays to fill the chip that way,
   // fewer for small batches so that more waves exist.
   const int64_t waves_needed = int64_t(c->cu_count) * 8;
@@ -791,6 +1037,102 @@ static int launch_cast(Ctx* c, const TriRec* tri, int64_t T, const float* rays, 
                            srect, int(T), bs, rays, R, t_hit, prim, uv);
       PQ_HIP(hipGetLastError());
       return 0;
+    }
+  }
+  if (varied && one_origin && cull && T >= 4 * kCluster && R >= 2) {
+    // ---- common origin: project onto the image plane, sort, cluster, culled sweep ------
+    double* d_sum = nullptr;
+    PQ_TRY(c->arena.get(3, &d_sum));
+    PQ_HIP(hipMemsetAsync(d_sum, 0, 24, c->stream));
+    hipLaunchKernelGGL(k_dir_sum, dim3(std::min<int64_t>(ceil_div(R, 256), 1024)), dim3(256), 0,
+                       c->stream, rays, R, d_sum);
+    double hs[3];
+    float ho[12];
+    PQ_HIP(hipMemcpyAsync(hs, d_sum, 24, hipMemcpyDeviceToHost, c->stream));
+    PQ_HIP(hipMemcpyAsync(ho, rays, 48, hipMemcpyDeviceToHost, c->stream));
+    PQ_HIP(hipStreamSynchronize(c->stream));
+    const double nn = std::sqrt(hs[0] * hs[0] + hs[1] * hs[1] + hs[2] * hs[2]);
+    if (nn > 1e-3 * double(R) && std::isfinite(nn)) {
+      const double n[3] = {hs[0] / nn, hs[1] / nn, hs[2] / nn};
+      // first image axis: the way consecutive rays turn (pixel rows become thin rectangles)
+      double a[3], an = 0.0;
+      {
+        // difference of the two rays' points on the plane n.x = 1 (lies in that plane whatever
+        // the lengths of the direction vectors are)
+        const double w0 = ho[3] * n[0] + ho[4] * n[1] + ho[5] * n[2];
+        const double w1 = ho[9] * n[0] + ho[10] * n[1] + ho[11] * n[2];
+        double s0[3] = {0, 0, 0};
+        if (w0 > 0 && w1 > 0)
+          for (int k = 0; k < 3; ++k) s0[k] = double(ho[9 + k]) / w1 - double(ho[3 + k]) / w0;
+        const double along = s0[0] * n[0] + s0[1] * n[1] + s0[2] * n[2];
+        for (int k = 0; k < 3; ++k) a[k] = s0[k] - along * n[k];
+        an = std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+      }
+      if (!(an > 1e-12)) {
+        double h[3] = {0, 0, 0};
+        const double ax = std::fabs(n[0]), ay = std::fabs(n[1]), az = std::fabs(n[2]);
+        h[ax <= ay && ax <= az ? 0 : (ay <= az ? 1 : 2)] = 1.0;
+        a[0] = n[1] * h[2] - n[2] * h[1];
+        a[1] = n[2] * h[0] - n[0] * h[2];
+        a[2] = n[0] * h[1] - n[1] * h[0];
+        an = std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+      }
+      for (double& q : a) q /= an;
+      const double b[3] = {n[1] * a[2] - n[2] * a[1], n[2] * a[0] - n[0] * a[2],
+                           n[0] * a[1] - n[1] * a[0]};
+      const Camera cam{ho[0], ho[1], ho[2], a[0], a[1], a[2], b[0], b[1], b[2], n[0], n[1], n[2]};
+      double* img = nullptr;
+      int* d_bad = nullptr;
+      PQ_TRY(c->arena.get(size_t(R) * 3, &img));
+      PQ_TRY(c->arena.get(1, &d_bad));
+      PQ_HIP(hipMemsetAsync(d_bad, 0, 4, c->stream));
+      hipLaunchKernelGGL(k_ray_image, dim3(ceil_div(R, 256)), dim3(256), 0, c->stream, rays, R, cam,
+                         0.25, img, d_bad);
+      PQ_HIP(hipGetLastError());
+      double mn[3], mx[3];
+      PQ_TRY(cloud_bbox(c, img, R, mn, mx));  // synchronises
+      int bad = 0;
+      PQ_HIP(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, c->stream));
+      PQ_HIP(hipStreamSynchronize(c->stream));
+      if (!bad) {
+        double ext = std::max(mx[0] - mn[0], mx[1] - mn[1]);
+        if (!(ext > 0)) ext = 1.0;
+        double* cen = nullptr;
+        float4 *rect = nullptr, *crect = nullptr, *srect = nullptr;
+        int32_t* sid = nullptr;
+        const int nclus = int((T + kCluster - 1) / kCluster);
+        const int nsup = (nclus + kSuper - 1) / kSuper;
+        PQ_TRY(c->arena.get(size_t(T) * 3, &cen));
+        PQ_TRY(c->arena.get(size_t(T), &rect));
+        PQ_TRY(c->arena.get(size_t(nclus), &crect));
+        PQ_TRY(c->arena.get(size_t(nsup), &srect));
+        PQ_TRY(c->arena.get(size_t(T), &sid));
+        hipLaunchKernelGGL(k_tri_image, dim3(ceil_div(T, 256)), dim3(256), 0, c->stream, tri, T, cam,
+                           mn[0], mx[0], mn[1], mx[1], cen, rect);
+        PQ_HIP(hipGetLastError());
+        double box[6] = {mn[0], mn[1], 0.0, mx[0], mx[1], 0.0};
+        DevGrid g;
+        PQ_TRY(build_grid(c, cen, T, ext / 1024.0, int64_t(1) << 22, &g, box));
+        const float margin = float(1e-4 * ext + 1e-30);
+        hipLaunchKernelGGL(k_clusters_image, dim3(ceil_div(nclus, 256)), dim3(256), 0, c->stream, int(T),
+                           g.order, rect, margin, sid, crect);
+        hipLaunchKernelGGL(k_super_rects, dim3(ceil_div(nsup, 256)), dim3(256), 0, c->stream, nclus,
+                           crect, srect);
+        PQ_HIP(hipGetLastError());
+        ProfScope ps(c, "cast_rays_culled");
+        if (np == 6) np = 4;
+        if (np == 4)
+          hipLaunchKernelGGL(k_cast_pinhole_culled<4>, grid_for(4), block, 0, c->stream, tri, sid, crect,
+                             srect, int(T), cam, rays, R, t_hit, prim, uv);
+        else if (np == 2)
+          hipLaunchKernelGGL(k_cast_pinhole_culled<2>, grid_for(2), block, 0, c->stream, tri, sid, crect,
+                             srect, int(T), cam, rays, R, t_hit, prim, uv);
+        else
+          hipLaunchKernelGGL(k_cast_pinhole_culled<1>, grid_for(1), block, 0, c->stream, tri, sid, crect,
+                             srect, int(T), cam, rays, R, t_hit, prim, uv);
+        PQ_HIP(hipGetLastError());
+        return 0;
+      }
     }
   }
   if (!varied) {

@@ -57,6 +57,35 @@ def test_parallel_rays_brute_force_and_culled_agree(gpu, monkeypatch):
     assert np.isfinite(t0).mean() > 0.2
 
 
+@pytest.mark.parametrize("eye", [(0.0, 0.0, 25.0),     # above the canopy, looking down
+                                 (0.5, -0.3, 9.0)])     # INSIDE the canopy: triangles all around,
+                                                        # behind the eye and across the eye plane
+def test_pinhole_rays_brute_force_and_culled_agree(gpu, monkeypatch, eye):
+    """Common-origin batches (the camera of cast_rays, ray_casting.py:269-279) through the
+    image-space culled sweep and through the plain brute-force kernel (PYQSM_RAY_CULL=0):
+    both must equal the oracle bit for bit (t, primitive id, uv)."""
+    from pyqsm_amd.viz.ray_casting import create_rays_pinhole
+    verts, tris = synth.canopy_mesh(20_000, seed=5, side=0.25)
+    rays = create_rays_pinhole(90.0, (0.0, 0.0, 9.0) if eye[2] > 20 else (3.0, 2.0, 9.5), eye,
+                               (0, 1, -1), 320, 240).reshape(-1, 6)
+    t0, p0, uv0 = oracle.cast_rays(verts, tris, rays)
+    for flag in ("1", "0"):
+        monkeypatch.setenv("PYQSM_RAY_CULL", flag)
+        t, p, uv = hip.cast_rays(verts, tris, rays, device=gpu)
+        assert np.array_equal(t, t0) and np.array_equal(p, p0) and np.array_equal(uv, uv0), flag
+    assert 0.05 < np.isfinite(t0).mean() < 1.0
+
+
+def test_common_origin_but_all_around_falls_back(gpu):
+    """One origin, directions over the whole sphere: no single image plane, so the batch takes
+    the brute-force kernel; results still equal the oracle."""
+    verts, tris = synth.canopy_mesh(5_000, seed=6, side=0.3)
+    rng = np.random.default_rng(0)
+    d = rng.normal(size=(20_000, 3)).astype(np.float32)
+    rays = np.concatenate([np.tile(np.float32([0.2, 0.1, 9.0]), (len(d), 1)), d], 1)
+    _check(verts, tris, rays, gpu)
+
+
 def test_unit_triangle_known_answers(gpu):
     verts = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], dtype=np.float32)
     tris = np.array([[0, 1, 2]], dtype=np.int32)
