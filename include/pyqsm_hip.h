@@ -211,6 +211,16 @@ int pyqsm_ball_query(const double* xyz, int64_t n, const double center[3], doubl
  */
 int pyqsm_radius_mark(const double* src, int64_t n, const double* qry, int64_t m, double radius,
                       int32_t k_cap, uint8_t* mark, int32_t* counts, int32_t device);
+/*
+ * The padded tables themselves — what scipy KDTree(src).query(qry, k,
+ * distance_upper_bound=radius) returns at pyQSM/geometry/reconstruction.py:238-240
+ * and get_neighbors_kdtree(return_pcd=False) hands to pyQSM/canopy_metrics.py:238:
+ * per query the (up to) k nearest source points with d < radius, ascending by
+ * (distance, index); missing entries are padded with distance +inf and index n.
+ *   idx i64 [m,k], dist f64 [m,k] (distances, not squared); 1 <= k <= 2048.
+ */
+int pyqsm_radius_knn(const double* src, int64_t n, const double* qry, int64_t m, double radius,
+                     int32_t k, int64_t* idx, double* dist, int32_t device);
 
 /* ---- farthest-point down-sampling ---------------------------------------- */
 /*

@@ -125,6 +125,145 @@ __global__ __launch_bounds__(256) void k_radius_mark(int m, const double* __rest
   (void)walk<2>(g, start, order, sx, sy, sz, x, y, z, r2, tau, budget, mark);
 }
 
+
+// ---- k nearest within a bound, as sorted padded tables (cKDTree.query semantics) --------
+// One wave per query. Count the source points inside the bound (64 candidates per step);
+// if there are more than k, find the k-th smallest squared distance exactly by bisection
+// on its bit pattern (rare: k defaults to 500 at a 5 cm bound); collect the survivors in
+// LDS, bitonic-sort them by (d2, index) and write k entries, padded with (inf, n).
+static constexpr int kKnnCap = 2048;  // largest k (LDS: 24 KB per wave)
+
+struct RowRuns {
+  int qb[9], qe[9];
+};
+
+__device__ __forceinline__ bool query_runs(const RGrid& g, const int32_t* __restrict__ start,
+                                           double x, double y, double z, RowRuns* rr) {
+  const int cx = int(floor((x - g.minx) * g.inv)) + 1;
+  const int cy = int(floor((y - g.miny) * g.inv)) + 1;
+  const int cz = int(floor((z - g.minz) * g.inv)) + 1;
+  if (cx < 0 || cy < 0 || cz < 0 || cx > g.nx - 1 || cy > g.ny - 1 || cz > g.nz - 1) return false;
+  int w = 0;
+  for (int dz = -1; dz <= 1; ++dz)
+    for (int dy = -1; dy <= 1; ++dy, ++w) {
+      const int zz = cz + dz, yy = cy + dy;
+      rr->qb[w] = rr->qe[w] = 0;
+      if (zz < 0 || zz >= g.nz || yy < 0 || yy >= g.ny) continue;
+      const int x0 = cx - 1 < 0 ? 0 : cx - 1, x1 = cx + 1 >= g.nx ? g.nx - 1 : cx + 1;
+      const int row = (zz * g.ny + yy) * g.nx;
+      rr->qb[w] = start[row + x0];
+      rr->qe[w] = start[row + x1 + 1];
+    }
+  return true;
+}
+
+__global__ __launch_bounds__(128) void k_radius_knn(int m, const double* __restrict__ qry, RGrid g,
+                                                    const int32_t* __restrict__ start,
+                                                    const int32_t* __restrict__ order,
+                                                    const double* __restrict__ sx,
+                                                    const double* __restrict__ sy,
+                                                    const double* __restrict__ sz, double r2, int k,
+                                                    int n_src, int64_t* __restrict__ out_idx,
+                                                    double* __restrict__ out_dist) {
+  __shared__ double sd[2][kKnnCap];
+  __shared__ int si[2][kKnnCap];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = blockIdx.x * 2 + w;
+  if (i >= m) return;  // whole wave
+  const double x = qry[3 * i], y = qry[3 * i + 1], z = qry[3 * i + 2];
+  RowRuns rr;
+  const bool inside = query_runs(g, start, x, y, z, &rr);
+  // count of candidates with d2 < r2 and d2 <= tau
+  auto count_le = [&](double tau) {
+    int cnt = 0;
+    for (int r = 0; r < 9; ++r)
+      for (int base = rr.qb[r]; base < rr.qe[r]; base += 64) {
+        const int q = base + lane;
+        bool in = false;
+        if (q < rr.qe[r]) {
+          const double d = sqd(x, y, z, sx[q], sy[q], sz[q]);
+          in = d < r2 && d <= tau;
+        }
+        cnt += __popcll(__ballot(in));
+      }
+    return cnt;
+  };
+  int total = inside ? count_le(__builtin_inf()) : 0;
+  double tau = __builtin_inf();
+  int budget = 0;  // ties at tau that still fit
+  if (total > k) {
+    unsigned long long lo = 0, hi = (unsigned long long)__double_as_longlong(r2);
+    while (lo < hi) {  // smallest t with #{d2 <= t} >= k
+      const unsigned long long mid = lo + ((hi - lo) >> 1);
+      if (count_le(__longlong_as_double((long long)mid)) >= k) hi = mid;
+      else lo = mid + 1;
+    }
+    tau = __longlong_as_double((long long)lo);
+    const int n_below = lo == 0 ? 0 : count_le(__longlong_as_double((long long)(lo - 1)));
+    budget = k - n_below;
+    total = k;
+  }
+  // collect (ties at tau in candidate order until the budget is used up)
+  int have = 0, ties = 0;
+  if (total > 0)
+    for (int r = 0; r < 9; ++r)
+      for (int base = rr.qb[r]; base < rr.qe[r]; base += 64) {
+        const int q = base + lane;
+        double d = 0.0;
+        bool below = false, tie = false;
+        if (q < rr.qe[r]) {
+          d = sqd(x, y, z, sx[q], sy[q], sz[q]);
+          below = d < r2 && d < tau;
+          tie = d < r2 && d == tau;
+        }
+        const unsigned long long tb = __ballot(tie);
+        const int tie_rank = ties + __popcll(tb & ((1ull << lane) - 1ull));
+        const bool take = below || (tie && tie_rank < budget);
+        const unsigned long long kb = __ballot(take);
+        if (take) {
+          const int slot = have + __popcll(kb & ((1ull << lane) - 1ull));
+          sd[w][slot] = d;
+          si[w][slot] = order[q];
+        }
+        have += __popcll(kb);
+        ties += __popcll(tb);
+      }
+  // pad to a power of two and sort by (d2, index)
+  int np2 = 1;
+  while (np2 < have) np2 <<= 1;
+  for (int t = have + lane; t < np2; t += 64) {
+    sd[w][t] = __builtin_inf();
+    si[w][t] = 0x7FFFFFFF;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  for (int k2 = 2; k2 <= np2; k2 <<= 1)
+    for (int j = k2 >> 1; j > 0; j >>= 1) {
+      for (int t = lane; t < np2; t += 64) {
+        const int u = t ^ j;
+        if (u > t) {
+          const double da = sd[w][t], db = sd[w][u];
+          const int ia = si[w][t], ib = si[w][u];
+          const bool a_gt_b = da > db || (da == db && ia > ib);
+          const bool up = (t & k2) == 0;
+          if (a_gt_b == up) {
+            sd[w][t] = db;
+            si[w][t] = ib;
+            sd[w][u] = da;
+            si[w][u] = ia;
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  for (int t = lane; t < k; t += 64) {
+    const bool real = t < have;
+    out_idx[size_t(i) * k + t] = real ? int64_t(si[w][t]) : int64_t(n_src);
+    out_dist[size_t(i) * k + t] = real ? sqrt(sd[w][t]) : __builtin_inf();
+  }
+}
+
 }  // namespace pyqsm
 
 using namespace pyqsm;
@@ -207,6 +346,49 @@ int pyqsm_radius_mark(const double* src, int64_t n, const double* qry, int64_t m
   }
   PQ_HIP(hipMemcpyAsync(mark, d_mark, size_t(n), hipMemcpyDeviceToHost, c->stream));
   PQ_HIP(hipMemcpyAsync(counts, d_counts, size_t(m) * 4, hipMemcpyDeviceToHost, c->stream));
+  PQ_HIP(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int pyqsm_radius_knn(const double* src, int64_t n, const double* qry, int64_t m, double radius,
+                     int32_t k, int64_t* idx, double* dist, int32_t device) {
+  if (n < 0 || m < 0) return fail(PYQSM_EINVAL, "negative size");
+  if (k <= 0 || k > kKnnCap) return fail(PYQSM_ERANGE, "k must be in [1, %d]", kKnnCap);
+  if (m > 0 && (!qry || !idx || !dist)) return fail(PYQSM_EINVAL, "pyqsm_radius_knn: NULL pointer");
+  if (n > 0 && !src) return fail(PYQSM_EINVAL, "pyqsm_radius_knn: NULL pointer");
+  if (!(radius > 0) || !std::isfinite(radius)) return fail(PYQSM_EINVAL, "radius must be positive");
+  if (m == 0) return 0;
+  if (m > 0x7FFFFF00LL || n > 0x7FFFFF00LL) return fail(PYQSM_ERANGE, "more than 2^31 points per call");
+  if (n == 0) {  // nothing to find: every slot is padding
+    for (int64_t t = 0; t < m * k; ++t) {
+      idx[t] = 0;
+      dist[t] = HUGE_VAL;
+    }
+    return 0;
+  }
+  Ctx* c = ctx_for(device);
+  if (!c) return PYQSM_ENODEV;
+  std::lock_guard<std::mutex> lk(c->mu);
+  c->arena.reset();
+  double *d_src, *d_qry, *d_dist;
+  int64_t* d_idx;
+  PQ_TRY(c->arena.get(size_t(n) * 3, &d_src));
+  PQ_TRY(c->arena.get(size_t(m) * 3, &d_qry));
+  PQ_TRY(c->arena.get(size_t(m) * k, &d_idx));
+  PQ_TRY(c->arena.get(size_t(m) * k, &d_dist));
+  PQ_HIP(hipMemcpyAsync(d_src, src, size_t(n) * 24, hipMemcpyHostToDevice, c->stream));
+  PQ_HIP(hipMemcpyAsync(d_qry, qry, size_t(m) * 24, hipMemcpyHostToDevice, c->stream));
+  DevGrid g;
+  PQ_TRY(build_grid(c, d_src, n, radius * (1.0 + 1.0 / 1048576.0), int64_t(1) << 28, &g));
+  RGrid rg{g.minx, g.miny, g.minz, g.inv_cell, g.nx, g.ny, g.nz};
+  {
+    ProfScope ps(c, "radius_knn");
+    hipLaunchKernelGGL(k_radius_knn, dim3(ceil_div(m, 2)), dim3(128), 0, c->stream, int(m), d_qry, rg,
+                       g.start, g.order, g.sx, g.sy, g.sz, radius * radius, k, int(n), d_idx, d_dist);
+    PQ_HIP(hipGetLastError());
+  }
+  PQ_HIP(hipMemcpyAsync(idx, d_idx, size_t(m) * k * 8, hipMemcpyDeviceToHost, c->stream));
+  PQ_HIP(hipMemcpyAsync(dist, d_dist, size_t(m) * k * 8, hipMemcpyDeviceToHost, c->stream));
   PQ_HIP(hipStreamSynchronize(c->stream));
   return 0;
 }

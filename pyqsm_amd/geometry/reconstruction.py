@@ -25,14 +25,14 @@ def get_neighbors_kdtree(src_pcd, query_pcd=None, query_pts=None, kd_tree=None, 
     sub-cloud, the number of neighbours each query selected (the reference returns the
     padded [m,k] index table here; its callers only use the other two values) and the
     ascending unique source indices; ``(None, None, None)`` when nothing is in range.
-    ``return_pcd=False`` (the full [m,k] distance/index tables) is not provided by the
-    GPU path. ``kd_tree`` is accepted and ignored."""
-    if not return_pcd:
-        raise NotImplementedError("get_neighbors_kdtree(return_pcd=False): the padded [m,k] "
-                                  "tables are not produced by the HIP radius kernel")
+    ``return_pcd=False`` returns ``(dists, nbrs)``, the padded [m,k] tables of
+    ``KDTree.query`` (missing entries: distance inf, index n), as canopy_metrics.py:238
+    uses them. ``kd_tree`` is accepted and ignored."""
     if query_pcd is not None:
         query_pts = as_points(query_pcd)
     src_pts = as_points(src_pcd)
+    if not return_pcd:
+        return hip.radius_knn(src_pts, as_points(query_pts), dist, k=k, device=device)
     mask, counts = hip.radius_mark(src_pts, as_points(query_pts), dist, k=k, device=device)
     uniques = np.flatnonzero(mask)
     if len(uniques) == 0:

@@ -333,6 +333,19 @@ def radius_mark(src, queries, radius: float, k: int = 500, device: int = 0):
 
 # ---------------------------------------------------------------- down-sampling
 
+def radius_knn(src, queries, radius: float, k: int = 500, device: int = 0):
+    """(dist f64 [m,k], idx int64 [m,k]) like ``cKDTree(src).query(queries, k,
+    distance_upper_bound=radius)``: ascending by (distance, index), padded with inf / n."""
+    s = _points(src)
+    q = _points(queries)
+    m = q.shape[0]
+    idx = np.empty((m, int(k)), dtype=np.int64)
+    dist = np.empty((m, int(k)), dtype=np.float64)
+    check(_lib.load().pyqsm_radius_knn(_p(s), s.shape[0], _p(q), m, float(radius), int(k), _p(idx),
+                                       _p(dist), int(device)))
+    return dist, idx
+
+
 def fps(points, num_samples: int, start_index: int = 0, device: int = 0) -> np.ndarray:
     """Farthest-point sampling: int32 indices in selection order."""
     pts = _points(points)

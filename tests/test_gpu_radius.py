@@ -60,3 +60,34 @@ def test_wrappers(gpu):
     t_sub = cKDTree(stem)
     pairs = cKDTree(P).query_ball_tree(t_sub, r=0.2)
     assert np.array_equal(idx, np.array([i for i, p in enumerate(pairs) if p]))
+
+
+@pytest.mark.parametrize("k,radius", [(8, 0.05), (40, 0.08), (500, 0.05), (3, 0.3)])
+def test_radius_knn_tables_match_ckdtree(gpu, k, radius):
+    """get_neighbors_kdtree(return_pcd=False) (canopy_metrics.py:238): the padded [m,k]
+    tables of cKDTree.query with a distance bound — distances bit-equal, indices equal
+    wherever the distances are distinct, padding (inf, n)."""
+    from scipy.spatial import cKDTree
+    from pyqsm_amd.geometry.reconstruction import get_neighbors_kdtree
+    rng = np.random.default_rng(k)
+    src = synth.forest(40_000, seed=3)
+    qry = np.concatenate([src[rng.choice(len(src), 3000, replace=False)] + rng.normal(0, 0.01, (3000, 3)),
+                          rng.uniform(-5, 5, (500, 3)),                 # mostly far from everything
+                          [[1e3, 1e3, 1e3]]])                           # outside the grid
+    qry = qry.astype(np.float32).astype(np.float64)
+    d0, i0 = cKDTree(src).query(qry, k=k, distance_upper_bound=radius)
+    d, i = get_neighbors_kdtree(src, query_pts=qry, dist=radius, k=k, return_pcd=False, device=gpu)
+    d0, i0 = d0.reshape(len(qry), k), i0.reshape(len(qry), k)
+    assert d.shape == d0.shape and i.dtype == np.int64
+    assert np.array_equal(d, d0)                       # includes the inf padding
+    assert np.array_equal(np.isinf(d), i == len(src))
+    # ties in distance may be ordered differently: compare per distinct distance
+    same = i == i0
+    if not same.all():
+        rows = np.flatnonzero(~same.all(1))
+        for r in rows:
+            assert sorted(zip(d[r], i[r])) == sorted(zip(d0[r], i0[r]))
+    full = np.isfinite(d[:, -1]).sum()
+    assert (np.isinf(d[:, 0])).sum() > 100             # some queries find nothing
+    if k <= 40:
+        assert full > 100                              # the k cap is exercised
