@@ -221,6 +221,16 @@ int pyqsm_radius_mark(const double* src, int64_t n, const double* qry, int64_t m
  */
 int pyqsm_radius_knn(const double* src, int64_t n, const double* qry, int64_t m, double radius,
                      int32_t k, int64_t* idx, double* dist, int32_t device);
+/*
+ * pyqsm_radius_mark with a label per query point: label[j] = the smallest label among
+ * the query points that select source point j (-1: none). One call replaces one cycle
+ * of the region growing of pyQSM/tree_isolation.py:207-256 (extend_seed_clusters), where
+ * clusters are visited in index order and the first one to reach a free point keeps it.
+ *   qry_label i32 [m] (>= 0); label i32 [n]; counts i32 [m] as in pyqsm_radius_mark.
+ */
+int pyqsm_radius_label(const double* src, int64_t n, const double* qry, int64_t m,
+                       const int32_t* qry_label, double radius, int32_t k_cap, int32_t* label,
+                       int32_t* counts, int32_t device);
 
 /* ---- farthest-point down-sampling ---------------------------------------- */
 /*

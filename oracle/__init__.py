@@ -365,3 +365,58 @@ def farthest_point_sampling(points, num_samples, start_index=0):
         dist = np.minimum(dist, d)
         sel = int(np.argmax(dist))          # first maximum
     return out
+
+
+# --------------------------------------------------------------------------
+# Region growing (pyQSM/tree_isolation.py:63-283)
+
+def extend_seed_clusters(seeds, src_pts, k=200, max_distance=.1, cycles=150, exclude_pts=None):
+    """The loop of tree_isolation.py:98-262 on SciPy's KD-tree, cluster by cluster and
+    with the ownership dict keyed by coordinate tuples, as the reference has it
+    (``order_cutoff=None``; no drawing / pickling). ``seeds`` = [(label, pts [m,3])].
+    Returns {label: float64 [p,3]} — seed points followed by the points acquired, in
+    acquisition order."""
+    from collections import defaultdict
+    import itertools
+    from scipy.spatial import cKDTree
+    src_pts = np.asarray(src_pts, dtype=np.float64)
+    assn = defaultdict(lambda: -1)
+    curr = []
+    for idc, (label, pts) in enumerate(seeds):
+        pts = np.asarray(pts, dtype=np.float64)
+        curr.append(pts)
+        for pt in pts:
+            assn[tuple(pt)] = idc                                          # :103-105
+    if exclude_pts is not None and len(exclude_pts):                       # :120-133
+        tree = cKDTree(src_pts)
+        _, nbrs = tree.query(np.asarray(exclude_pts, dtype=np.float64), k=k,
+                             distance_upper_bound=max_distance)
+        drop = {x for x in itertools.chain.from_iterable(np.atleast_2d(nbrs)) if x != len(src_pts)}
+        keep = np.ones(len(src_pts), dtype=bool)
+        keep[list(drop)] = False
+        src_pts = src_pts[keep]
+    tree = cKDTree(src_pts)
+    num_pts = len(src_pts)
+    complete = []
+    for cycle_num in range(cycles):
+        for idx in range(len(seeds)):
+            if idx in complete:
+                continue
+            if len(curr[idx]) > 0:
+                _, nbrs = tree.query(curr[idx], k=k, distance_upper_bound=max_distance)   # :207-209
+                nbrs = sorted({int(x) for x in itertools.chain.from_iterable(np.atleast_2d(nbrs))
+                               if x != num_pts})
+                nbr_pts = [src_pts[nb] for nb in nbrs if assn[tuple(src_pts[nb])] == -1]
+                if len(nbr_pts) > 0:
+                    for pt in nbr_pts:
+                        assn[tuple(pt)] = idx
+                    curr[idx] = np.asarray(nbr_pts)
+                    if len(curr[idx]) < 5:                                 # :256-258
+                        complete.append(idx)
+            if len(curr[idx]) == 0:
+                complete.append(idx)
+    out = defaultdict(list)
+    for pt, idc in assn.items():
+        if idc >= 0:
+            out[seeds[idc][0]].append(pt)
+    return {label: np.asarray(pts, dtype=np.float64).reshape(-1, 3) for label, pts in out.items()}

@@ -51,6 +51,7 @@ SIGNATURES = {
     "pyqsm_clamp": (ctypes.c_int, [vp, i64, vp, vp, i32]),
     "pyqsm_ball_query": (ctypes.c_int, [vp, i64, vp, dbl, vp, ctypes.POINTER(i64), i32]),
     "pyqsm_radius_mark": (ctypes.c_int, [vp, i64, vp, i64, dbl, i32, vp, vp, i32]),
+    "pyqsm_radius_label": (ctypes.c_int, [vp, i64, vp, i64, vp, dbl, i32, vp, vp, i32]),
     "pyqsm_radius_knn": (ctypes.c_int, [vp, i64, vp, i64, dbl, i32, vp, vp, i32]),
     "pyqsm_fps": (ctypes.c_int, [vp, i64, i64, i64, vp, i32]),
     "pyqsm_pc_laplacian": (ctypes.c_int, [vp, i64, i32, dbl, ctypes.POINTER(i64),

@@ -58,7 +58,8 @@ __device__ __forceinline__ int walk(const RGrid& g, const int32_t* __restrict__ 
                                     const int32_t* __restrict__ order,
                                     const double* __restrict__ sx, const double* __restrict__ sy,
                                     const double* __restrict__ sz, double x, double y, double z,
-                                    double r2, double tau, int budget, uint8_t* __restrict__ mark) {
+                                    double r2, double tau, int budget, uint8_t* __restrict__ mark,
+                                    int32_t* __restrict__ lab_out = nullptr, int lab = 0) {
   int cx = int(floor((x - g.minx) * g.inv)) + 1;
   int cy = int(floor((y - g.miny) * g.inv)) + 1;
   int cz = int(floor((z - g.minz) * g.inv)) + 1;
@@ -78,11 +79,14 @@ __device__ __forceinline__ int walk(const RGrid& g, const int32_t* __restrict__ 
         if (MODE == 0) cnt += d < r2;
         if (MODE == 1) cnt += d < r2 && d <= tau;
         if (MODE == 2) {
-          if (d < r2 && d < tau) {
-            mark[order[q]] = 1;
-          } else if (d < r2 && d == tau && cnt < budget) {  // ties at the k-th distance
-            mark[order[q]] = 1;
+          bool take = d < r2 && d < tau;
+          if (!take && d < r2 && d == tau && cnt < budget) {  // ties at the k-th distance
+            take = true;
             ++cnt;
+          }
+          if (take) {
+            if (lab_out) atomicMin(&lab_out[order[q]], lab);
+            else mark[order[q]] = 1;
           }
         }
       }
@@ -98,10 +102,14 @@ __global__ __launch_bounds__(256) void k_radius_mark(int m, const double* __rest
                                                      const double* __restrict__ sy,
                                                      const double* __restrict__ sz, double r2,
                                                      int k, uint8_t* __restrict__ mark,
-                                                     int32_t* __restrict__ counts) {
+                                                     int32_t* __restrict__ counts,
+                                                     const int32_t* __restrict__ qlab /*may be null*/,
+                                                     int32_t* __restrict__ lab_out) {
   int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= m) return;
   const double x = qry[3 * i], y = qry[3 * i + 1], z = qry[3 * i + 2];
+  int32_t* lo_ = qlab ? lab_out : nullptr;
+  const int lab = qlab ? qlab[i] : 0;
   const int c = walk<0>(g, start, order, sx, sy, sz, x, y, z, r2, 0.0, 0, mark);
   counts[i] = c < k ? c : k;
   if (c == 0) return;
@@ -122,7 +130,7 @@ __global__ __launch_bounds__(256) void k_radius_mark(int m, const double* __rest
     const int n_below = lo == 0 ? 0 : walk<1>(g, start, order, sx, sy, sz, x, y, z, r2, below, 0, mark);
     budget = k - n_below;
   }
-  (void)walk<2>(g, start, order, sx, sy, sz, x, y, z, r2, tau, budget, mark);
+  (void)walk<2>(g, start, order, sx, sy, sz, x, y, z, r2, tau, budget, mark, lo_, lab);
 }
 
 
@@ -341,7 +349,7 @@ int pyqsm_radius_mark(const double* src, int64_t n, const double* qry, int64_t m
     ProfScope ps(c, "radius_mark");
     hipLaunchKernelGGL(k_radius_mark, dim3(ceil_div(m, 256)), dim3(256), 0, c->stream, int(m), d_qry,
                        rg, g.start, g.order, g.sx, g.sy, g.sz, radius * radius, k_cap, d_mark,
-                       d_counts);
+                       d_counts, static_cast<const int32_t*>(nullptr), static_cast<int32_t*>(nullptr));
     PQ_HIP(hipGetLastError());
   }
   PQ_HIP(hipMemcpyAsync(mark, d_mark, size_t(n), hipMemcpyDeviceToHost, c->stream));
@@ -390,6 +398,56 @@ int pyqsm_radius_knn(const double* src, int64_t n, const double* qry, int64_t m,
   PQ_HIP(hipMemcpyAsync(idx, d_idx, size_t(m) * k * 8, hipMemcpyDeviceToHost, c->stream));
   PQ_HIP(hipMemcpyAsync(dist, d_dist, size_t(m) * k * 8, hipMemcpyDeviceToHost, c->stream));
   PQ_HIP(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int pyqsm_radius_label(const double* src, int64_t n, const double* qry, int64_t m,
+                       const int32_t* qry_label, double radius, int32_t k_cap, int32_t* label,
+                       int32_t* counts, int32_t device) {
+  if (n < 0 || m < 0) return fail(PYQSM_EINVAL, "negative size");
+  if (n > 0 && (!src || !label)) return fail(PYQSM_EINVAL, "pyqsm_radius_label: NULL pointer");
+  if (m > 0 && (!qry || !qry_label || !counts))
+    return fail(PYQSM_EINVAL, "pyqsm_radius_label: NULL pointer");
+  if (!(radius > 0) || !std::isfinite(radius)) return fail(PYQSM_EINVAL, "radius must be positive");
+  if (k_cap <= 0) return fail(PYQSM_EINVAL, "k must be positive");
+  for (int64_t i = 0; i < n; ++i) label[i] = -1;
+  if (m > 0) memset(counts, 0, size_t(m) * 4);
+  if (n == 0 || m == 0) return 0;
+  for (int64_t i = 0; i < m; ++i)
+    if (qry_label[i] < 0) return fail(PYQSM_EINVAL, "query labels must be >= 0");
+  if (m > 0x7FFFFF00LL) return fail(PYQSM_ERANGE, "more than 2^31 query points per call");
+  Ctx* c = ctx_for(device);
+  if (!c) return PYQSM_ENODEV;
+  std::lock_guard<std::mutex> lk(c->mu);
+  c->arena.reset();
+  double *d_src, *d_qry;
+  int32_t *d_lab, *d_counts, *d_qlab;
+  uint8_t* d_mark;
+  PQ_TRY(c->arena.get(size_t(n) * 3, &d_src));
+  PQ_TRY(c->arena.get(size_t(m) * 3, &d_qry));
+  PQ_TRY(c->arena.get(size_t(n), &d_lab));
+  PQ_TRY(c->arena.get(size_t(m), &d_counts));
+  PQ_TRY(c->arena.get(size_t(m), &d_qlab));
+  PQ_TRY(c->arena.get(1, &d_mark));
+  PQ_HIP(hipMemcpyAsync(d_src, src, size_t(n) * 24, hipMemcpyHostToDevice, c->stream));
+  PQ_HIP(hipMemcpyAsync(d_qry, qry, size_t(m) * 24, hipMemcpyHostToDevice, c->stream));
+  PQ_HIP(hipMemcpyAsync(d_qlab, qry_label, size_t(m) * 4, hipMemcpyHostToDevice, c->stream));
+  PQ_HIP(hipMemsetAsync(d_lab, 0x7F, size_t(n) * 4, c->stream));  // 0x7F7F7F7F > any label
+  DevGrid g;
+  PQ_TRY(build_grid(c, d_src, n, radius * (1.0 + 1.0 / 1048576.0), int64_t(1) << 28, &g));
+  RGrid rg{g.minx, g.miny, g.minz, g.inv_cell, g.nx, g.ny, g.nz};
+  {
+    ProfScope ps(c, "radius_label");
+    hipLaunchKernelGGL(k_radius_mark, dim3(ceil_div(m, 256)), dim3(256), 0, c->stream, int(m), d_qry,
+                       rg, g.start, g.order, g.sx, g.sy, g.sz, radius * radius, k_cap, d_mark,
+                       d_counts, d_qlab, d_lab);
+    PQ_HIP(hipGetLastError());
+  }
+  PQ_HIP(hipMemcpyAsync(label, d_lab, size_t(n) * 4, hipMemcpyDeviceToHost, c->stream));
+  PQ_HIP(hipMemcpyAsync(counts, d_counts, size_t(m) * 4, hipMemcpyDeviceToHost, c->stream));
+  PQ_HIP(hipStreamSynchronize(c->stream));
+  for (int64_t i = 0; i < n; ++i)
+    if (label[i] == 0x7F7F7F7F) label[i] = -1;
   return 0;
 }
 

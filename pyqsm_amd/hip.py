@@ -333,6 +333,22 @@ def radius_mark(src, queries, radius: float, k: int = 500, device: int = 0):
 
 # ---------------------------------------------------------------- down-sampling
 
+def radius_label(src, queries, query_labels, radius: float, k: int = 500, device: int = 0):
+    """int32 [n]: for every source point the smallest label among the query points that
+    select it (k nearest within ``radius``, strict), -1 where none does; and the per-query
+    neighbour counts."""
+    s = _points(src)
+    q = _points(queries)
+    ql = np.ascontiguousarray(query_labels, dtype=np.int32).reshape(-1)
+    if ql.shape[0] != q.shape[0]:
+        raise ValueError("one label per query point")
+    lab = np.empty(max(s.shape[0], 1), dtype=np.int32)
+    counts = np.zeros(max(q.shape[0], 1), dtype=np.int32)
+    check(_lib.load().pyqsm_radius_label(_p(s), s.shape[0], _p(q), q.shape[0], _p(ql), float(radius),
+                                         int(k), _p(lab), _p(counts), int(device)))
+    return lab[:s.shape[0]], counts[:q.shape[0]]
+
+
 def radius_knn(src, queries, radius: float, k: int = 500, device: int = 0):
     """(dist f64 [m,k], idx int64 [m,k]) like ``cKDTree(src).query(queries, k,
     distance_upper_bound=radius)``: ascending by (distance, index), padded with inf / n."""
