@@ -520,12 +520,14 @@ __global__ __launch_bounds__(256) void k_update_r(int n, const double* __restric
   reduce3_atomic(rr[0], rr[1], rr[2], sc->rr[par]);
 }
 
-static constexpr int kAmgBurst = 2;  // iterations per graph replay / residual check
+static constexpr int kAmgFirstBurst = 8;  // a 1e-2 solve takes 10-14 iterations: no look before 8
+static constexpr int kAmgBurst = 2;       // then a residual check every 2
 
 // CG on B y = rhs preconditioned by one multigrid V-cycle (amg.hip). Same device-side
 // scalar protocol as jacobi_pcg: an iteration is the sparse pass, the update, the cycle
-// (its last kernel also accumulates r.z) and the direction update, replayed as a graph
-// two iterations at a time; the host only reads |r|^2 between replays. y starts at 0.
+// (its last kernel also accumulates r.z) and the direction update, replayed as graphs of 8
+// and then 2 iterations; the host only reads |b|^2 and |r|^2 between replays (each look
+// costs a stream drain, which is what small systems are bound by). y starts at 0.
 static int amg_pcg(Ctx* c, const System& S, const Work& w, AmgHierarchy* H, const double* rhs,
                    double* y, double rtol, int32_t max_it, GraphCache* cache, int32_t* iters,
                    double resid[3]) {
@@ -537,12 +539,8 @@ static int amg_pcg(Ctx* c, const System& S, const Work& w, AmgHierarchy* H, cons
   hipLaunchKernelGGL(k_dot3, grid, block, 0, c->stream, N, rhs, rhs, w.sc->bb);
   PQ_TRY(amg_vcycle(c, H, w.r, w.z, w.sc->rz[0]));
   PQ_HIP(hipMemcpyAsync(w.dir, w.z, size_t(N) * 24, hipMemcpyDeviceToDevice, c->stream));
-  double bb[3];
-  PQ_HIP(hipMemcpyAsync(bb, w.sc->bb, 24, hipMemcpyDeviceToHost, c->stream));
-  PQ_HIP(hipStreamSynchronize(c->stream));
-  for (int k = 0; k < 3; ++k) resid[k] = bb[k] > 0 ? 1.0 : 0.0;
+  for (int k = 0; k < 3; ++k) resid[k] = 1.0;
   *iters = 0;
-  if (bb[0] == 0.0 && bb[1] == 0.0 && bb[2] == 0.0) return 0;
   auto iteration = [&](int par) -> int {
     hipLaunchKernelGGL(k_spmv3_tail<OP_B>, grid, block, 0, c->stream, N, S.L.indptr, S.L.indices,
                        S.L.vals, w.dir, static_cast<const double*>(nullptr), S.c, S.wh, w.dir, w.q,
@@ -552,37 +550,51 @@ static int amg_pcg(Ctx* c, const System& S, const Work& w, AmgHierarchy* H, cons
     hipLaunchKernelGGL(k_direction, grid, block, 0, c->stream, N, w.z, w.dir, w.sc, par);
     return 0;
   };
-  hipGraphExec_t exec = nullptr;
   if (getenv("PYQSM_NO_GRAPH")) cache = nullptr;  // plain launches (profilers that cannot follow graphs)
-  if (cache)
-    for (auto& g : cache->items)
-      if (g.b == static_cast<const void*>(H) && g.x == y && g.op == 2) exec = g.exec;
+  // graphs are keyed by (hierarchy, target vector, burst length)
+  auto run_burst = [&](int len) -> int {
+    hipGraphExec_t exec = nullptr;
+    if (cache)
+      for (auto& g : cache->items)
+        if (g.b == static_cast<const void*>(H) && g.x == y && g.op == 100 + len) exec = g.exec;
+    if (cache && !exec) {
+      hipGraph_t graph = nullptr;
+      PQ_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
+      int rc = 0;
+      for (int bi = 0; bi < len && rc == 0; ++bi) rc = iteration(bi & 1);
+      PQ_HIP(hipStreamEndCapture(c->stream, &graph));
+      if (rc != 0) return rc;
+      PQ_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+      (void)hipGraphDestroy(graph);
+      cache->items.push_back({static_cast<const void*>(H), y, 100 + len, exec});
+    }
+    if (exec) {
+      PQ_HIP(hipGraphLaunch(exec, c->stream));
+    } else {
+      for (int bi = 0; bi < len; ++bi) PQ_TRY(iteration(bi & 1));
+    }
+    return 0;
+  };
   int it = 0;
   bool done = false;
   while (!done && it < max_it) {
+    int len = it == 0 ? kAmgFirstBurst : kAmgBurst;
+    if (len > max_it - it) len = std::max(2, (max_it - it + 1) & ~1);  // even: bursts start at parity 0
     {
-      ProfScope ps(c, "lbc_amg_iter", kAmgBurst);
-      if (cache && !exec) {
-        hipGraph_t graph = nullptr;
-        PQ_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
-        int rc = 0;
-        for (int bi = 0; bi < kAmgBurst && rc == 0; ++bi) rc = iteration(bi & 1);
-        PQ_HIP(hipStreamEndCapture(c->stream, &graph));
-        if (rc != 0) return rc;
-        PQ_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-        (void)hipGraphDestroy(graph);
-        cache->items.push_back({static_cast<const void*>(H), y, 2, exec});
-      }
-      if (exec) {
-        PQ_HIP(hipGraphLaunch(exec, c->stream));
-      } else {
-        for (int bi = 0; bi < kAmgBurst; ++bi) PQ_TRY(iteration(bi & 1));
-      }
+      ProfScope ps(c, "lbc_amg_iter", len);
+      PQ_TRY(run_burst(len));
     }
-    it += kAmgBurst;
-    double rr[3];
-    PQ_HIP(hipMemcpyAsync(rr, &w.sc->rr[1][0], 24, hipMemcpyDeviceToHost, c->stream));
+    it += len;
+    double h[6];  // rr[1][0..2], bb[0..2] are adjacent in Scal
+    PQ_HIP(hipMemcpyAsync(h, &w.sc->rr[1][0], 48, hipMemcpyDeviceToHost, c->stream));
     PQ_HIP(hipStreamSynchronize(c->stream));
+    const double* rr = h;
+    const double* bb = h + 3;
+    if (bb[0] == 0.0 && bb[1] == 0.0 && bb[2] == 0.0) {  // zero right-hand side: y = 0
+      for (int k = 0; k < 3; ++k) resid[k] = 0.0;
+      *iters = it;
+      return 0;
+    }
     done = true;
     for (int k = 0; k < 3; ++k) {
       resid[k] = bb[k] > 0 ? std::sqrt(rr[k] / bb[k]) : 0.0;
