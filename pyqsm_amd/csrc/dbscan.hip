@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void k_core_tiled(int n, Stencil st, int ncell
   const bool live = p < n;
   const double x = live ? sx[p] : 0.0, y = live ? sy[p] : 0.0, z = live ? sz[p] : 0.0;
   const Tile t = wave_tile(p0, n, st, ncell, start, cell_of);
-  int cnt = 0;
+  int cnt = 0;  // (starting lanes of sub-cells with >= min_pts points as "decided" gained nothing)
   bool deferred = false;
   if (t.total > kTileMax) {  // per-lane fallback
     if (live) {
@@ -433,6 +433,43 @@ __global__ __launch_bounds__(256) void k_union_sub(const int32_t* __restrict__ l
   }
 }
 
+// ---- fallback for coarsened grids ----------------------------------------------------
+// When the cloud's extent would need more than 2^28 cells of edge eps, grid.hip doubles the
+// edge; a sub-cell is then wider than eps and says nothing about connectivity. Such clouds
+// take the per-point union-find of the first version (same results, ~3x slower union phase).
+__global__ __launch_bounds__(256) void k_union_points(int n, Stencil st,
+                                                      const int32_t* __restrict__ start,
+                                                      const int32_t* __restrict__ cell_of,
+                                                      const double* __restrict__ sx,
+                                                      const double* __restrict__ sy,
+                                                      const double* __restrict__ sz, double r2,
+                                                      const uint8_t* __restrict__ core, int* parent) {
+  int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= n || !core[p]) return;
+  const double x = sx[p], y = sy[p], z = sz[p];
+  const int c = cell_of[p];
+  const volatile int* vparent = parent;
+  int rp = find_root(parent, p);
+  FOR_STENCIL(c, st, start, q, {
+    // each unordered pair once; a plain read equal to p's root proves "same tree"
+    if (q < p && core[q] && sqdist(x, y, z, sx[q], sy[q], sz[q]) <= r2) {
+      if (vparent[q] != rp) {
+        unite(parent, p, q);
+        rp = find_root(parent, p);
+      }
+    }
+  })
+}
+
+__global__ __launch_bounds__(256) void k_point_min(int n, const uint8_t* __restrict__ core,
+                                                   const int* __restrict__ parent,
+                                                   const int32_t* __restrict__ order,
+                                                   int* __restrict__ min_orig) {
+  int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= n || !core[p]) return;
+  atomicMin(min_orig + parent[p], order[p]);  // k_flatten ran: parent[p] is the root
+}
+
 // Smallest original core index of every component, folded from the per-run minima of
 // the representatives (k_sub_rep): 5x fewer values than points, wave-folded when the
 // wave's representatives share a root (the common case), and an atomic only if it can
@@ -538,6 +575,8 @@ static int dbscan_device(Ctx* c, const double* xyz, int64_t n, double eps, int32
     PQ_TRY(build_grid(c, xyz, n, eps * (1.0 + 1.0 / 1048576.0), int64_t(1) << 28, &g));
     PQ_TRY(subsort_octants(c, &g, n, &sub));
   }
+  // the sub-cell shortcuts need cells of edge eps (not doubled to fit the dense grid)
+  const bool fine = g.cell <= eps * (1.0 + 1.0 / 524288.0);
   const int N = int(n);
   const dim3 grid(ceil_div(n, 256)), block(256);
   const Stencil st{g.nx, g.nx * g.ny};
@@ -574,34 +613,42 @@ static int dbscan_device(Ctx* c, const double* xyz, int64_t n, double eps, int32
     hipLaunchKernelGGL(k_init_parent, grid, block, 0, c->stream, N, parent);
     PQ_HIP(hipMemsetAsync(min_orig, 0x7F, size_t(n) * 4, c->stream));  // 0x7F7F7F7F > any index
     PQ_HIP(hipMemsetAsync(flag, 0, (size_t(n) + 1) * 4, c->stream));
-    PQ_HIP(hipMemsetAsync(list_cnt, 0, 4, c->stream));
-    hipLaunchKernelGGL(k_sub_rep, grid, block, 0, c->stream, N, sub.sub_of, sub.sub_beg, sub.sub_cnt,
-                       core, g.order, parent, sub_rep, run_min, list, list_cnt);
-    int32_t m = 0;
-    PQ_HIP(hipMemcpyAsync(&m, list_cnt, 4, hipMemcpyDeviceToHost, c->stream));
-    PQ_HIP(hipStreamSynchronize(c->stream));
-    if (m > 0) {
-      const dim3 gw(ceil_div(m, 4)), gl(ceil_div(m, 256));
-      {
-        ProfScope pk(c, "k_hook_sub");
-        hipLaunchKernelGGL(k_hook_sub, gw, block, 0, c->stream, list, m, g.nx, g.ny, g.start, g.cell_of,
-                           sub.sub_of, sub.sub_beg, sub.sub_cnt, sub_rep, g.sx, g.sy, g.sz, r2, core,
-                           parent);
+    if (fine) {
+      PQ_HIP(hipMemsetAsync(list_cnt, 0, 4, c->stream));
+      hipLaunchKernelGGL(k_sub_rep, grid, block, 0, c->stream, N, sub.sub_of, sub.sub_beg, sub.sub_cnt,
+                         core, g.order, parent, sub_rep, run_min, list, list_cnt);
+      int32_t m = 0;
+      PQ_HIP(hipMemcpyAsync(&m, list_cnt, 4, hipMemcpyDeviceToHost, c->stream));
+      PQ_HIP(hipStreamSynchronize(c->stream));
+      if (m > 0) {
+        const dim3 gw(ceil_div(m, 4)), gl(ceil_div(m, 256));
+        {
+          ProfScope pk(c, "k_hook_sub");
+          hipLaunchKernelGGL(k_hook_sub, gw, block, 0, c->stream, list, m, g.nx, g.ny, g.start, g.cell_of,
+                             sub.sub_of, sub.sub_beg, sub.sub_cnt, sub_rep, g.sx, g.sy, g.sz, r2, core,
+                             parent);
+        }
+        hipLaunchKernelGGL(k_flatten_reps, gl, block, 0, c->stream, list, m, parent);
+        // what is left: joining the few trees per cluster. Almost every pair of neighbours
+        // now shows the same root through two plain loads.
+        {
+          ProfScope pk(c, "k_union_sub");
+          hipLaunchKernelGGL(k_union_sub, gw, block, 0, c->stream, list, m, 0, 62, g.nx, g.ny, g.start,
+                             g.cell_of, sub.sub_of, sub.sub_beg, sub.sub_cnt, sub_rep, g.sx, g.sy, g.sz, r2,
+                             core, parent);
+        }
+        hipLaunchKernelGGL(k_flatten_reps, gl, block, 0, c->stream, list, m, parent);
+        hipLaunchKernelGGL(k_rep_min, gl, block, 0, c->stream, list, m, parent, run_min, min_orig);
       }
-      hipLaunchKernelGGL(k_flatten_reps, gl, block, 0, c->stream, list, m, parent);
-      // what is left: joining the few trees per cluster. Almost every pair of neighbours
-      // now shows the same root through two plain loads.
-      {
-        ProfScope pk(c, "k_union_sub");
-        hipLaunchKernelGGL(k_union_sub, gw, block, 0, c->stream, list, m, 0, 62, g.nx, g.ny, g.start,
-                           g.cell_of, sub.sub_of, sub.sub_beg, sub.sub_cnt, sub_rep, g.sx, g.sy, g.sz, r2,
-                           core, parent);
-      }
-      hipLaunchKernelGGL(k_flatten_reps, gl, block, 0, c->stream, list, m, parent);
-      hipLaunchKernelGGL(k_rep_min, gl, block, 0, c->stream, list, m, parent, run_min, min_orig);
+      PQ_HIP(hipGetLastError());
+      hipLaunchKernelGGL(k_flatten, grid, block, 0, c->stream, N, core, parent);
+    } else {
+      hipLaunchKernelGGL(k_union_points, grid, block, 0, c->stream, N, st, g.start, g.cell_of, g.sx, g.sy,
+                         g.sz, r2, core, parent);
+      hipLaunchKernelGGL(k_flatten, grid, block, 0, c->stream, N, core, parent);
+      hipLaunchKernelGGL(k_point_min, grid, block, 0, c->stream, N, core, parent, g.order, min_orig);
+      PQ_HIP(hipGetLastError());
     }
-    PQ_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_flatten, grid, block, 0, c->stream, N, core, parent);
     hipLaunchKernelGGL(k_mark_roots, grid, block, 0, c->stream, N, core, parent, min_orig, flag);
     PQ_HIP(hipGetLastError());
     PQ_TRY(exclusive_scan_i32(c, flag, n + 1));

@@ -116,3 +116,16 @@ def test_planar_and_single_cell(gpu):
     P = np.concatenate([rng.uniform(0, 1, (8000, 2)), np.zeros((8000, 1))], 1)
     _check(P, 0.02, 4, gpu)                         # z extent zero
     _check(rng.uniform(0, 0.01, (500, 3)), 1.0, 5, gpu)   # eps far above the extent: one cell
+
+
+def test_extent_far_beyond_the_dense_grid(gpu):
+    """Extent / eps so large that the cell edge is doubled several times to fit the dense grid:
+    cells (and octant sub-cells) are then wider than eps and the sub-cell shortcuts must not
+    be used. Many small clusters inside single cells plus outliers 100 units away."""
+    rng = np.random.default_rng(11)
+    blob = rng.uniform(0, 0.6, (6000, 3))
+    far = rng.uniform(-50, 50, (40, 3))
+    P = np.concatenate([blob, far]).astype(np.float32).astype(np.float64)
+    lab, core = _check(P, 0.03, 4, gpu)
+    assert lab.max() > 5 and (lab == -1).sum() > 40 and (~core & (lab >= 0)).sum() > 0
+    _check(P, 0.012, 1, gpu)
