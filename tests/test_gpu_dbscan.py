@@ -129,3 +129,30 @@ def test_extent_far_beyond_the_dense_grid(gpu):
     lab, core = _check(P, 0.03, 4, gpu)
     assert lab.max() > 5 and (lab == -1).sum() > 40 and (~core & (lab >= 0)).sum() > 0
     _check(P, 0.012, 1, gpu)
+
+
+def test_randomised_differential(gpu):
+    """Sixty small random configurations (sizes, densities, shapes, duplicates, lattices,
+    min_pts from 1 up) against the sequential oracle."""
+    rng = np.random.default_rng(2024)
+    for case in range(60):
+        n = int(rng.integers(1, 3000))
+        kind = case % 5
+        if kind == 0:
+            P = rng.uniform(0, 1, (n, 3))
+        elif kind == 1:                                   # blobs of very different density
+            centres = rng.uniform(0, 1, (6, 3))
+            P = centres[rng.integers(0, 6, n)] + rng.normal(0, 1, (n, 3)) * rng.choice([0.005, 0.02, 0.08], (n, 1))
+        elif kind == 2:                                   # planar / linear
+            P = rng.uniform(0, 1, (n, 3)) * [1, rng.choice([0, 1]), 0]
+        elif kind == 3:                                   # lattice with duplicates, exact spacing
+            P = rng.integers(0, 12, (n, 3)) * 0.0625
+        else:                                             # wide extent: coarsened grid
+            P = np.concatenate([rng.uniform(0, 0.3, (n, 3)), rng.uniform(-40, 40, (3, 3))])
+        P = P.astype(np.float32).astype(np.float64)
+        eps = float(rng.choice([0.0625, 0.03, 0.1, 0.011]))
+        min_pts = int(rng.choice([1, 2, 3, 5, 10, 30]))
+        lab, core = hip.dbscan(P, eps, min_pts, device=gpu)
+        lab0, core0 = oracle.dbscan(P, eps, min_pts)
+        assert np.array_equal(core, core0), (case, n, eps, min_pts)
+        assert np.array_equal(lab, lab0), (case, n, eps, min_pts)
