@@ -166,3 +166,24 @@ def test_list_intersections_vs_oracle(gpu):
     t, _, _ = hip.cast_rays(verts, tris, rays, device=gpu)
     for r in np.flatnonzero(got["counts"])[:50]:
         assert t[r] == got["t_hit"][got["ray_ids"] == r].min()
+
+
+def test_randomised_cameras_and_sun_angles(gpu):
+    """Twelve random pinhole cameras (eye inside or outside the canopy, various fields of
+    view) and six random sun directions over a small canopy: both culled paths against the
+    oracle, bit for bit."""
+    from pyqsm_amd.viz.ray_casting import create_rays_pinhole
+    rng = np.random.default_rng(77)
+    verts, tris = synth.canopy_mesh(6_000, seed=8, side=0.3)
+    lo, hi = verts.min(0), verts.max(0)
+    for case in range(12):
+        eye = rng.uniform(lo - 3, hi + 3)
+        center = rng.uniform(lo, hi)
+        up = rng.normal(size=3)
+        fov = float(rng.choice([20.0, 60.0, 90.0, 120.0]))
+        rays = create_rays_pinhole(fov, center, eye, up, 96, 64).reshape(-1, 6)
+        _check(verts, tris, rays, gpu)
+    for case in range(6):
+        rays = synth.sun_rays(verts, 30_000, elevation_deg=float(rng.uniform(5, 89)),
+                              azimuth_deg=float(rng.uniform(0, 360)))
+        _check(verts, tris, rays, gpu)
