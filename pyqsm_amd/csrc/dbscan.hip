@@ -71,6 +71,10 @@ struct TileLds {
 // the wave leaves. In a dense cloud that is after 2-4 of the ~13 chunks; without the
 // straggler list one noise point would hold its whole wave to the end.
 static constexpr int kStragglers = 6;
+// ... and after kMaxChunks chunks everybody still short goes there, whatever their number: a
+// tile can hold 5000 candidates (80 chunks) and a wave that cannot leave early was the tail
+// that set the kernel's duration (average wave 21 us, kernel 300 us).
+static constexpr int kMaxChunks = 8;
 // centre, same-z rows, same-y rows, corners (compile-time: the run bounds stay in SGPRs)
 __device__ constexpr int kRunOrder[9] = {4, 3, 5, 1, 7, 0, 2, 6, 8};
 
@@ -94,10 +98,40 @@ __global__ __launch_bounds__(256) void k_core_tiled(int n, Stencil st, int ncell
   const Tile t = wave_tile(p0, n, st, ncell, start, cell_of);
   int cnt = 0;  // (starting lanes of sub-cells with >= min_pts points as "decided" gained nothing)
   bool deferred = false;
-  if (t.total > kTileMax) {  // per-lane fallback
-    if (live) {
-      const int c = cell_of[p];
-      FOR_STENCIL(c, st, start, q, { cnt += sqdist(x, y, z, sx[q], sy[q], sz[q]) <= r2; })
+  int chunks = 0;
+  if (t.total > kTileMax) {
+    // The wave's points straddle distant cells (end of one grid layer, start of the next):
+    // the linear intervals would sweep whole layers. Take the distinct cells of the wave
+    // one at a time instead — exact 27-cell stencil, candidates still staged through LDS,
+    // only the lanes of that cell count. (A per-lane walk here made these few waves the
+    // 0.25 ms tail of the whole kernel: ~850 dependent gathers per lane.)
+    const int mycell = live ? cell_of[p] : -1;
+    unsigned long long todo = __ballot(live);
+    while (todo) {
+      const int lead = __ffsll(todo) - 1;
+      const int c = __builtin_amdgcn_readlane(mycell, lead);
+      const bool mine = mycell == c;
+      todo &= ~__ballot(mine);
+      for (int dz = -1; dz <= 1; ++dz)
+        for (int dy = -1; dy <= 1; ++dy) {
+          const int row = c + dy * st.nx + dz * st.nxy;
+          const int qb = __builtin_amdgcn_readfirstlane(start[row - 1]);
+          const int qe = __builtin_amdgcn_readfirstlane(start[row + 2]);
+          for (int base = qb; base < qe; base += 64) {
+            const int q = base + lane;
+            const int m = qe - base < 64 ? qe - base : 64;
+            if (q < qe) {
+              L.x[w][lane] = sx[q];
+              L.y[w][lane] = sy[q];
+              L.z[w][lane] = sz[q];
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (mine)
+              for (int j = 0; j < m; ++j)
+                cnt += sqdist(x, y, z, L.x[w][j], L.y[w][j], L.z[w][j]) <= r2;
+            __builtin_amdgcn_wave_barrier();
+          }
+        }
     }
   } else {
 #pragma unroll
@@ -117,7 +151,9 @@ __global__ __launch_bounds__(256) void k_core_tiled(int n, Stencil st, int ncell
           cnt += sqdist(x, y, z, L.x[w][j], L.y[w][j], L.z[w][j]) <= r2;
         __builtin_amdgcn_wave_barrier();
         const unsigned long long und = __ballot(live && cnt < min_pts);
-        if (__popcll(und) <= kStragglers && !(ri == 8 && base + 64 >= t.qe[r])) {
+        ++chunks;
+        if ((__popcll(und) <= kStragglers || chunks >= kMaxChunks) &&
+            !(ri == 8 && base + 64 >= t.qe[r])) {
           // the few lanes still short restart on their own in k_core_rest
           if (und != 0) {
             int slot = 0;
