@@ -74,7 +74,7 @@ static constexpr int kStragglers = 6;
 // ... and after kMaxChunks chunks everybody still short goes there, whatever their number: a
 // tile can hold 5000 candidates (80 chunks) and a wave that cannot leave early was the tail
 // that set the kernel's duration (average wave 21 us, kernel 300 us).
-static constexpr int kMaxChunks = 8;
+static constexpr int kMaxChunks = 6;
 // centre, same-z rows, same-y rows, corners (compile-time: the run bounds stay in SGPRs)
 __device__ constexpr int kRunOrder[9] = {4, 3, 5, 1, 7, 0, 2, 6, 8};
 
@@ -277,16 +277,17 @@ __global__ __launch_bounds__(256) void k_sub_rep(int n, const int32_t* __restric
                                                  const uint8_t* __restrict__ core,
                                                  const int32_t* __restrict__ order,
                                                  int* __restrict__ parent,
-                                                 int32_t* __restrict__ sub_rep,
+                                                 const int32_t* __restrict__ cell_of,
+                                                 int4* __restrict__ rec,
                                                  int* __restrict__ run_min,
-                                                 int32_t* __restrict__ list,
+                                                 int4* __restrict__ list,
                                                  int32_t* __restrict__ list_cnt) {
   int p = blockIdx.x * 256 + threadIdx.x;
-  int rep = -1;
+  int rep = -1, sid = 0, e = 0;
   if (p < n) {
-    const int sid = sub_of[p];
+    sid = sub_of[p];
     if (sub_beg[sid] == p) {
-      const int e = p + sub_cnt[sid];
+      e = p + sub_cnt[sid];
       int mn = 0x7FFFFFFF;
       for (int q = p; q < e; ++q)
         if (core[q]) {
@@ -294,8 +295,10 @@ __global__ __launch_bounds__(256) void k_sub_rep(int n, const int32_t* __restric
           parent[q] = rep;
           mn = min(mn, order[q]);
         }
-      sub_rep[sid] = rep;
-      if (rep >= 0) run_min[rep] = mn;  // smallest original index among the run's core points
+      if (rep >= 0) {
+        rec[sid].z = rep;
+        run_min[rep] = mn;  // smallest original index among the run's core points
+      }
     }
   }
   // block-aggregated append of the representatives: one atomic per block (atomics on a
@@ -314,7 +317,9 @@ __global__ __launch_bounds__(256) void k_sub_rep(int n, const int32_t* __restric
     wbase[3] = base + wcount[0] + wcount[1] + wcount[2];
   }
   __syncthreads();
-  if (rep >= 0) list[wbase[w] + __popcll(b & ((1ull << lane) - 1ull))] = rep;
+  // list record: representative, its cell, its sub-cell id, points from it to the run's end
+  if (rep >= 0)
+    list[wbase[w] + __popcll(b & ((1ull << lane) - 1ull))] = make_int4(rep, cell_of[rep], sid, e - rep);
 }
 
 // The 62 lexicographically positive (dz, dy, dx) offsets in [-2,2]^3 as (dx, dy, dz): the 13
@@ -324,11 +329,11 @@ __constant__ signed char kSubOffsets[62][3] = {{1,0,0}, {-1,1,0}, {0,1,0}, {1,1,
 // Full path compression for the listed representatives (plain accesses: the kernel
 // boundary makes the unions of the previous launch visible, and any value another lane
 // writes meanwhile is an ancestor too).
-__global__ __launch_bounds__(256) void k_flatten_reps(const int32_t* __restrict__ list, int m,
+__global__ __launch_bounds__(256) void k_flatten_reps(const int4* __restrict__ list, int m,
                                                       int* __restrict__ parent) {
   int s = blockIdx.x * 256 + threadIdx.x;
   if (s >= m) return;
-  const int p = list[s];
+  const int p = list[s].x;
   int r = p;
   for (int nx = parent[r]; nx != r; nx = parent[r]) r = nx;
   parent[p] = r;
@@ -340,13 +345,9 @@ __global__ __launch_bounds__(256) void k_flatten_reps(const int32_t* __restrict_
 // no cycle, every sub-cell writes its own pointer only (plain store, no atomics, no
 // chasing), and what remains after compression is a few trees per cluster — one per
 // sub-cell without a connected smaller neighbour. One wave per sub-cell as below.
-__global__ __launch_bounds__(256) void k_hook_sub(const int32_t* __restrict__ list, int m, int nx,
+__global__ __launch_bounds__(256) void k_hook_sub(const int4* __restrict__ list, int m, int nx,
                                                   int ny, const int32_t* __restrict__ start,
-                                                  const int32_t* __restrict__ cell_of,
-                                                  const int32_t* __restrict__ sub_of,
-                                                  const int32_t* __restrict__ sub_beg,
-                                                  const int32_t* __restrict__ sub_cnt,
-                                                  const int32_t* __restrict__ sub_rep,
+                                                  const int4* __restrict__ rec,
                                                   const double* __restrict__ sx,
                                                   const double* __restrict__ sy,
                                                   const double* __restrict__ sz, double r2,
@@ -355,9 +356,8 @@ __global__ __launch_bounds__(256) void k_hook_sub(const int32_t* __restrict__ li
   const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (s >= m) return;  // wave-uniform
   const int k = threadIdx.x & 63;
-  const int p = list[s];
-  const int c1 = cell_of[p], sid1 = sub_of[p], o1 = sid1 & 7;
-  const int n1 = sub_beg[sid1] + sub_cnt[sid1] - p;  // p is the first core point of its run
+  const int4 me = list[s];  // one 16-byte load instead of three dependent ones
+  const int p = me.x, c1 = me.y, o1 = me.z & 7, n1 = me.w;
   const int cx = c1 % nx, cy = (c1 / nx) % ny, cz = c1 / (nx * ny);
   int q0 = 0, n2 = 0, rep2 = -1;
   if (k < 62) {
@@ -367,11 +367,11 @@ __global__ __launch_bounds__(256) void k_hook_sub(const int32_t* __restrict__ li
     const int c2 = (((gz >> 1) + 1) * ny + ((gy >> 1) + 1)) * nx + ((gx >> 1) + 1);
     const int b2 = start[c2];
     if (start[c2 + 1] != b2) {
-      const int sid2 = b2 * 8 + ((gx & 1) | ((gy & 1) << 1) | ((gz & 1) << 2));
-      n2 = sub_cnt[sid2];
-      if (n2 > 0) {
-        rep2 = sub_rep[sid2];
-        q0 = sub_beg[sid2];
+      const int4 r = rec[b2 * 8 + ((gx & 1) | ((gy & 1) << 1) | ((gz & 1) << 2))];
+      if (r.y > 0) {
+        q0 = r.x;
+        n2 = r.y;
+        rep2 = r.z;
       }
     }
   }
@@ -404,14 +404,10 @@ __global__ __launch_bounds__(256) void k_hook_sub(const int32_t* __restrict__ li
 // neighbours that do one at a time and tests all |S1| x |S2| point pairs at once, 64 per
 // step. (A lane per pair of sub-cells running the pair loop itself was 3x slower: ~25
 // dependent iterations per lane, and a wave lasts as long as its slowest lane.)
-__global__ __launch_bounds__(256) void k_union_sub(const int32_t* __restrict__ list, int m, int k0,
+__global__ __launch_bounds__(256) void k_union_sub(const int4* __restrict__ list, int m, int k0,
                                                    int k1, int nx, int ny,
                                                    const int32_t* __restrict__ start,
-                                                   const int32_t* __restrict__ cell_of,
-                                                   const int32_t* __restrict__ sub_of,
-                                                   const int32_t* __restrict__ sub_beg,
-                                                   const int32_t* __restrict__ sub_cnt,
-                                                   const int32_t* __restrict__ sub_rep,
+                                                   const int4* __restrict__ rec,
                                                    const double* __restrict__ sx,
                                                    const double* __restrict__ sy,
                                                    const double* __restrict__ sz, double r2,
@@ -419,9 +415,8 @@ __global__ __launch_bounds__(256) void k_union_sub(const int32_t* __restrict__ l
   const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (s >= m) return;  // wave-uniform
   const int k = threadIdx.x & 63;
-  const int p = list[s];
-  const int c1 = cell_of[p], sid1 = sub_of[p], o1 = sid1 & 7;
-  const int n1 = sub_beg[sid1] + sub_cnt[sid1] - p;  // p is the first core point of its run
+  const int4 me = list[s];
+  const int p = me.x, c1 = me.y, o1 = me.z & 7, n1 = me.w;
   const int cx = c1 % nx, cy = (c1 / nx) % ny, cz = c1 / (nx * ny);
   int q0 = 0, n2 = 0, rep2 = -1;
   bool need = false;
@@ -433,11 +428,11 @@ __global__ __launch_bounds__(256) void k_union_sub(const int32_t* __restrict__ l
     const int c2 = (((gz >> 1) + 1) * ny + ((gy >> 1) + 1)) * nx + ((gx >> 1) + 1);
     const int b2 = start[c2];
     if (start[c2 + 1] != b2) {
-      const int sid2 = b2 * 8 + ((gx & 1) | ((gy & 1) << 1) | ((gz & 1) << 2));
-      n2 = sub_cnt[sid2];
-      if (n2 > 0) {
-        rep2 = sub_rep[sid2];
-        q0 = sub_beg[sid2];
+      const int4 r = rec[b2 * 8 + ((gx & 1) | ((gy & 1) << 1) | ((gz & 1) << 2))];
+      if (r.y > 0) {
+        q0 = r.x;
+        n2 = r.y;
+        rep2 = r.z;
       }
     }
     if (rep2 >= 0) {
@@ -511,7 +506,7 @@ __global__ __launch_bounds__(256) void k_point_min(int n, const uint8_t* __restr
 // wave's representatives share a root (the common case), and an atomic only if it can
 // still lower the stored minimum. (Folding all core points this way cost 0.23 ms per
 // million points: atomics and coherent loads on a handful of hot addresses.)
-__global__ __launch_bounds__(256) void k_rep_min(const int32_t* __restrict__ list, int m,
+__global__ __launch_bounds__(256) void k_rep_min(const int4* __restrict__ list, int m,
                                                  const int* __restrict__ parent,
                                                  const int* __restrict__ run_min,
                                                  int* __restrict__ min_orig) {
@@ -519,7 +514,7 @@ __global__ __launch_bounds__(256) void k_rep_min(const int32_t* __restrict__ lis
   const bool active = s < m;
   int r = -1, v = 0x7FFFFFFF;
   if (active) {
-    const int p = list[s];
+    const int p = list[s].x;
     r = parent[p];  // k_flatten_reps ran: the root
     v = run_min[p];
   }
@@ -624,10 +619,10 @@ static int dbscan_device(Ctx* c, const double* xyz, int64_t n, double eps, int32
   PQ_TRY(c->arena.get(size_t(n), &parent));
   PQ_TRY(c->arena.get(size_t(n), &min_orig));
   PQ_TRY(c->arena.get(size_t(n) + 1, &flag));
-  int32_t *sub_rep, *list, *list_cnt;
+  int4* list;
+  int32_t* list_cnt;
   int* run_min;
   PQ_TRY(c->arena.get(size_t(n), &run_min));
-  PQ_TRY(c->arena.get(size_t(n) * 8, &sub_rep));
   PQ_TRY(c->arena.get(size_t(n), &list));
   PQ_TRY(c->arena.get(2, &list_cnt));
   int32_t* rest;
@@ -652,7 +647,7 @@ static int dbscan_device(Ctx* c, const double* xyz, int64_t n, double eps, int32
     if (fine) {
       PQ_HIP(hipMemsetAsync(list_cnt, 0, 4, c->stream));
       hipLaunchKernelGGL(k_sub_rep, grid, block, 0, c->stream, N, sub.sub_of, sub.sub_beg, sub.sub_cnt,
-                         core, g.order, parent, sub_rep, run_min, list, list_cnt);
+                         core, g.order, parent, g.cell_of, sub.rec, run_min, list, list_cnt);
       int32_t m = 0;
       PQ_HIP(hipMemcpyAsync(&m, list_cnt, 4, hipMemcpyDeviceToHost, c->stream));
       PQ_HIP(hipStreamSynchronize(c->stream));
@@ -660,9 +655,8 @@ static int dbscan_device(Ctx* c, const double* xyz, int64_t n, double eps, int32
         const dim3 gw(ceil_div(m, 4)), gl(ceil_div(m, 256));
         {
           ProfScope pk(c, "k_hook_sub");
-          hipLaunchKernelGGL(k_hook_sub, gw, block, 0, c->stream, list, m, g.nx, g.ny, g.start, g.cell_of,
-                             sub.sub_of, sub.sub_beg, sub.sub_cnt, sub_rep, g.sx, g.sy, g.sz, r2, core,
-                             parent);
+          hipLaunchKernelGGL(k_hook_sub, gw, block, 0, c->stream, list, m, g.nx, g.ny, g.start, sub.rec,
+                             g.sx, g.sy, g.sz, r2, core, parent);
         }
         hipLaunchKernelGGL(k_flatten_reps, gl, block, 0, c->stream, list, m, parent);
         // what is left: joining the few trees per cluster. Almost every pair of neighbours
@@ -670,8 +664,7 @@ static int dbscan_device(Ctx* c, const double* xyz, int64_t n, double eps, int32
         {
           ProfScope pk(c, "k_union_sub");
           hipLaunchKernelGGL(k_union_sub, gw, block, 0, c->stream, list, m, 0, 62, g.nx, g.ny, g.start,
-                             g.cell_of, sub.sub_of, sub.sub_beg, sub.sub_cnt, sub_rep, g.sx, g.sy, g.sz, r2,
-                             core, parent);
+                             sub.rec, g.sx, g.sy, g.sz, r2, core, parent);
         }
         hipLaunchKernelGGL(k_flatten_reps, gl, block, 0, c->stream, list, m, parent);
         hipLaunchKernelGGL(k_rep_min, gl, block, 0, c->stream, list, m, parent, run_min, min_orig);

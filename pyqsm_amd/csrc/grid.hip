@@ -305,14 +305,17 @@ __global__ __launch_bounds__(256) void k_sub_count(int n, GridParams g,
 __global__ __launch_bounds__(256) void k_sub_prefix(int n, const int32_t* __restrict__ start,
                                                     const int32_t* __restrict__ cell_of,
                                                     const int32_t* __restrict__ sub_cnt,
-                                                    int32_t* __restrict__ sub_beg) {
+                                                    int32_t* __restrict__ sub_beg,
+                                                    int4* __restrict__ rec) {
   int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= n || start[cell_of[p]] != p) return;
   int run = p;
 #pragma unroll
   for (int o = 0; o < 8; ++o) {
+    const int cnt = sub_cnt[size_t(p) * 8 + o];
     sub_beg[size_t(p) * 8 + o] = run;
-    run += sub_cnt[size_t(p) * 8 + o];
+    rec[size_t(p) * 8 + o] = make_int4(run, cnt, -1, 0);
+    run += cnt;
   }
 }
 
@@ -348,6 +351,7 @@ int subsort_octants(Ctx* c, DevGrid* g, int64_t n, SubCells* sub) {
   PQ_TRY(c->arena.get(size_t(n) * 8, &sub->sub_cnt));
   PQ_TRY(c->arena.get(size_t(n) * 8, &sub->sub_beg));
   PQ_TRY(c->arena.get(size_t(n), &sub->sub_of));
+  PQ_TRY(c->arena.get(size_t(n) * 8, &sub->rec));
   PQ_TRY(c->arena.get(size_t(n), &oct_rank));
   PQ_TRY(c->arena.get(size_t(n), &order2));
   PQ_TRY(c->arena.get(size_t(n), &sx2));
@@ -359,7 +363,7 @@ int subsort_octants(Ctx* c, DevGrid* g, int64_t n, SubCells* sub) {
   hipLaunchKernelGGL(k_sub_count, grid, blk, 0, c->stream, int(n), gp, g->start, g->cell_of, g->sx,
                      g->sy, g->sz, sub->sub_cnt, oct_rank);
   hipLaunchKernelGGL(k_sub_prefix, grid, blk, 0, c->stream, int(n), g->start, g->cell_of,
-                     sub->sub_cnt, sub->sub_beg);
+                     sub->sub_cnt, sub->sub_beg, sub->rec);
   hipLaunchKernelGGL(k_sub_scatter, grid, blk, 0, c->stream, int(n), g->start, g->cell_of, oct_rank,
                      sub->sub_beg, g->order, g->sx, g->sy, g->sz, order2, sx2, sy2, sz2, sub->sub_of);
   PQ_HIP(hipGetLastError());

@@ -114,6 +114,7 @@ struct SubCells {
   int32_t* sub_cnt;  // [8 n]
   int32_t* sub_beg;  // [8 n]
   int32_t* sub_of;   // [n] sub-cell id of each sorted position
+  int4* rec;         // [8 n] (sub_beg, sub_cnt, -1, 0) in one 16-byte record; .z is the caller's
 };
 
 // Re-sorts g's point arrays in place (order, sx, sy, sz are replaced by new arena arrays;
