@@ -557,37 +557,72 @@ __global__ __launch_bounds__(256) void k_mark_roots(int n, const uint8_t* __rest
   if (parent[p] == p) flag[min_orig[p]] = 1;
 }
 
-__global__ __launch_bounds__(256) void k_labels(int n, Stencil st,
-                                                const int32_t* __restrict__ start,
-                                                const int32_t* __restrict__ cell_of,
-                                                const double* __restrict__ sx,
-                                                const double* __restrict__ sy,
-                                                const double* __restrict__ sz, double r2,
-                                                const uint8_t* __restrict__ core,
+// Labels of the core points; the others (noise and border candidates, a few percent) are
+// listed for k_labels_border. (Walking the stencil per lane here made those few points the
+// tail of the kernel: ~850 dependent gathers each.)
+__global__ __launch_bounds__(256) void k_labels(int n, const uint8_t* __restrict__ core,
                                                 const int* __restrict__ parent,
                                                 const int* __restrict__ min_orig,
                                                 const int32_t* __restrict__ rank,
                                                 const int32_t* __restrict__ order,
                                                 int64_t* __restrict__ labels,
-                                                uint8_t* __restrict__ is_core) {
+                                                uint8_t* __restrict__ is_core,
+                                                int32_t* __restrict__ rest,
+                                                int32_t* __restrict__ rest_cnt) {
   int p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= n) return;
-  int best = kNoRoot;
-  if (core[p]) {
-    best = min_orig[parent[p]];
-  } else {
+  const bool live = p < n;
+  const bool is_c = live && core[p];
+  if (is_c) labels[order[p]] = int64_t(rank[min_orig[parent[p]]]);
+  if (live && is_core) is_core[order[p]] = is_c;
+  const unsigned long long nb = __ballot(live && !is_c);
+  if (nb == 0) return;
+  const int lane = threadIdx.x & 63, lead = __ffsll(nb) - 1;
+  int slot = 0;
+  if (lane == lead) slot = atomicAdd(rest_cnt, __popcll(nb));
+  slot = __shfl(slot, lead, 64);
+  if (live && !is_c) rest[slot + __popcll(nb & ((1ull << lane) - 1ull))] = p;
+}
+
+// One WAVE per non-core point: smallest cluster number among its core neighbours, or -1.
+__global__ __launch_bounds__(256) void k_labels_border(const int32_t* __restrict__ rest,
+                                                       const int32_t* __restrict__ rest_cnt,
+                                                       Stencil st, const int32_t* __restrict__ start,
+                                                       const int32_t* __restrict__ cell_of,
+                                                       const double* __restrict__ sx,
+                                                       const double* __restrict__ sy,
+                                                       const double* __restrict__ sz, double r2,
+                                                       const uint8_t* __restrict__ core,
+                                                       const int* __restrict__ parent,
+                                                       const int* __restrict__ min_orig,
+                                                       const int32_t* __restrict__ rank,
+                                                       const int32_t* __restrict__ order,
+                                                       int64_t* __restrict__ labels) {
+  const int m = *rest_cnt;
+  const int lane = threadIdx.x & 63;
+  for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < m; i += gridDim.x * 4) {  // wave-uniform
+    const int p = rest[i];
     const double x = sx[p], y = sy[p], z = sz[p];
     const int c = cell_of[p];
-    FOR_STENCIL(c, st, start, q, {
-      if (core[q] && sqdist(x, y, z, sx[q], sy[q], sz[q]) <= r2) {
-        int m = min_orig[parent[q]];
-        best = m < best ? m : best;
+    int best = kNoRoot;
+    for (int dz = -1; dz <= 1; ++dz)
+      for (int dy = -1; dy <= 1; ++dy) {
+        const int row = c + dy * st.nx + dz * st.nxy;
+        const int qe = start[row + 2];
+        for (int base = start[row - 1]; base < qe; base += 64) {
+          const int q = base + lane;
+          if (q < qe && core[q] && sqdist(x, y, z, sx[q], sy[q], sz[q]) <= r2) {
+            const int mo = min_orig[parent[q]];
+            best = mo < best ? mo : best;
+          }
+        }
       }
-    })
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const int o = __shfl_xor(best, off, 64);
+      best = o < best ? o : best;
+    }
+    if (lane == 0) labels[order[p]] = best == kNoRoot ? int64_t(-1) : int64_t(rank[best]);
   }
-  const int o = order[p];
-  labels[o] = best == kNoRoot ? int64_t(-1) : int64_t(rank[best]);
-  if (is_core) is_core[o] = core[p];
 }
 
 static int dbscan_device(Ctx* c, const double* xyz, int64_t n, double eps, int32_t min_pts,
@@ -684,8 +719,12 @@ static int dbscan_device(Ctx* c, const double* xyz, int64_t n, double eps, int32
   }
   {
     ProfScope ps(c, "dbscan_label");
-    hipLaunchKernelGGL(k_labels, grid, block, 0, c->stream, N, st, g.start, g.cell_of, g.sx, g.sy,
-                       g.sz, r2, core, parent, min_orig, flag, g.order, labels, is_core);
+    PQ_HIP(hipMemsetAsync(list_cnt + 1, 0, 4, c->stream));
+    hipLaunchKernelGGL(k_labels, grid, block, 0, c->stream, N, core, parent, min_orig, flag, g.order,
+                       labels, is_core, rest, list_cnt + 1);
+    hipLaunchKernelGGL(k_labels_border, dim3(std::min<int64_t>(8192, ceil_div(n, 64))), block, 0,
+                       c->stream, rest, list_cnt + 1, st, g.start, g.cell_of, g.sx, g.sy, g.sz, r2, core,
+                       parent, min_orig, flag, g.order, labels);
     PQ_HIP(hipGetLastError());
   }
   if (n_clusters) {
