@@ -139,6 +139,114 @@ __global__ __launch_bounds__(T) void k_knn(int n_query, const int32_t* __restric
 }
 
 
+// Level-0 search for k <= 32: the same per-lane shell walk, but the sorted best-K list lives
+// in REGISTERS (K = k rounded up to 8/16/24/32; unrolled, branch-free insertion) instead
+// of a 12*k-byte LDS column per lane. At k = 20 the LDS columns allow two blocks per CU
+// (two waves per SIMD) and the walk is a chain of dependent gathers: occupancy is what it
+// needs. Slots beyond k only make the acceptance test slightly more generous.
+template <int K>
+__global__ __launch_bounds__(256) void k_knn_reg(int n_query, KnnGrid g,
+                                                 const int32_t* __restrict__ start,
+                                                 const int32_t* __restrict__ order,
+                                                 const int32_t* __restrict__ cell_of,
+                                                 const double* __restrict__ sx,
+                                                 const double* __restrict__ sy,
+                                                 const double* __restrict__ sz, int k,
+                                                 int exclude_self, int n_total, int last_level,
+                                                 int32_t* __restrict__ out_idx,
+                                                 double* __restrict__ out_d2,
+                                                 int32_t* __restrict__ fail_list,
+                                                 int32_t* __restrict__ fail_count) {
+  const int p = blockIdx.x * 256 + threadIdx.x;  // sorted position of this query
+  if (p >= n_query) return;
+  const int self = order[p];
+  const double x = sx[p], y = sy[p], z = sz[p];
+  const int c = cell_of[p];
+  const int cx = c % g.nx, cy = (c / g.nx) % g.ny, cz = c / (g.nx * g.ny);
+  double bd[K];
+  int bi[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    bd[j] = __builtin_inf();
+    bi[j] = 0x7FFFFFFF;
+  }
+  bool done = false;
+  const int rmax_grid = max(g.nx, max(g.ny, g.nz));
+  for (int r = 0; r <= kMaxRing && !done; ++r) {
+    for (int dz = -r; dz <= r; ++dz) {
+      const int zz = cz + dz;
+      if (zz < 0 || zz >= g.nz) continue;
+      for (int dy = -r; dy <= r; ++dy) {
+        const int yy = cy + dy;
+        if (yy < 0 || yy >= g.ny) continue;
+        const int row = (zz * g.ny + yy) * g.nx;
+        const bool full = (dz == -r || dz == r || dy == -r || dy == r);
+        const int nseg = full ? 1 : (r > 0 ? 2 : 1);
+        for (int s = 0; s < nseg; ++s) {
+          int x0, x1;
+          if (full) {
+            x0 = cx - r;
+            x1 = cx + r;
+          } else {
+            x0 = x1 = s == 0 ? cx - r : cx + r;
+          }
+          x0 = x0 < 0 ? 0 : x0;
+          x1 = x1 >= g.nx ? g.nx - 1 : x1;
+          if (x0 > x1) continue;
+          const int qb = start[row + x0], qe = start[row + x1 + 1];
+          for (int q = qb; q < qe; ++q) {
+            if (exclude_self && q == p) continue;
+            const double d = sqdist3(x, y, z, sx[q], sy[q], sz[q]);
+            if (!(d < bd[K - 1] || d == bd[K - 1])) continue;  // cheap reject before the id load
+            const int id = order[q];
+            bool lt_cur = d < bd[K - 1] || (d == bd[K - 1] && id < bi[K - 1]);
+            if (!lt_cur) continue;
+#pragma unroll
+            for (int t = K - 1; t > 0; --t) {
+              const bool lt_prev = d < bd[t - 1] || (d == bd[t - 1] && id < bi[t - 1]);
+              bd[t] = lt_prev ? bd[t - 1] : (lt_cur ? d : bd[t]);
+              bi[t] = lt_prev ? bi[t - 1] : (lt_cur ? id : bi[t]);
+              lt_cur = lt_prev;
+            }
+            bd[0] = lt_cur ? d : bd[0];
+            bi[0] = lt_cur ? id : bi[0];
+          }
+        }
+      }
+    }
+    // everything outside the visited cube is at least r cells away
+    double kth = __builtin_inf();
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+      if (j == k - 1) kth = bd[j];
+    const double safe = double(r) * g.cell * 0.999999;
+    if (kth <= safe * safe) done = true;
+    if (r >= rmax_grid) done = true;  // the cube already covers the whole grid
+  }
+  if (!done && !last_level) {
+    fail_list[atomicAdd(fail_count, 1)] = self;
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < K; ++j)
+    if (j < k) {
+      const bool have = bd[j] < __builtin_inf();
+      out_idx[size_t(self) * k + j] = have ? bi[j] : n_total;
+      out_d2[size_t(self) * k + j] = bd[j];
+    }
+}
+
+template <int K>
+static int launch_knn_reg(Ctx* c, int n, const DevGrid& g, int k, int excl, int last, int32_t* idx,
+                          double* d2, int32_t* fail_list, int32_t* fail_count) {
+  KnnGrid kg{g.nx, g.ny, g.nz, g.cell};
+  hipLaunchKernelGGL(k_knn_reg<K>, dim3(ceil_div(n, 256)), dim3(256), 0, c->stream, n, kg, g.start,
+                     g.order, g.cell_of, g.sx, g.sy, g.sz, k, excl, n, last, idx, d2, fail_list,
+                     fail_count);
+  PQ_HIP(hipGetLastError());
+  return 0;
+}
+
 // Wave-per-query variant for the retry levels (k <= 64): there the cells are
 // coarse and hold thousands of points, so the 64 lanes scan a run together.
 // The sorted best-k list lives in registers, element j in lane j; an insertion
@@ -328,7 +436,16 @@ int knn_device(Ctx* c, const double* xyz, int64_t n, int32_t k, int32_t exclude_
     {
       ProfScope ps(c, level == 0 ? "knn_search" : "knn_retry");
       int32_t* fl = (level & 1) ? fail_b : fail_a;
-      if (level > 0 && k <= 64) {
+      if (level == 0 && k <= 32) {
+        if (k <= 8)
+          PQ_TRY(launch_knn_reg<8>(c, N, g, k, exclude_self, last, idx, d2, fl, fail_count));
+        else if (k <= 16)
+          PQ_TRY(launch_knn_reg<16>(c, N, g, k, exclude_self, last, idx, d2, fl, fail_count));
+        else if (k <= 24)
+          PQ_TRY(launch_knn_reg<24>(c, N, g, k, exclude_self, last, idx, d2, fl, fail_count));
+        else
+          PQ_TRY(launch_knn_reg<32>(c, N, g, k, exclude_self, last, idx, d2, fl, fail_count));
+      } else if (level > 0 && k <= 64) {
         KnnGrid kg{g.nx, g.ny, g.nz, g.cell};
         hipLaunchKernelGGL(k_knn_wave, dim3(ceil_div(n_query, 4)), dim3(256), 0, c->stream, n_query,
                            list, pos_of, kg, g.start, g.order, g.cell_of, g.sx, g.sy, g.sz, k,
