@@ -30,6 +30,10 @@
 namespace pyqsm {
 
 static constexpr int kMaxRing = 3;
+// From the second retry level on the (wave-per-query) search may walk this many shells:
+// what is still open there are a handful of far outliers, and one more 4x coarsening would
+// make each of them scan whole trees (4 queries took 1.25 ms on the 1 M-point forest).
+static constexpr int kWideRing = 8;
 static constexpr int kMaxK = 192;
 
 struct KnnGrid {
@@ -261,7 +265,7 @@ __global__ __launch_bounds__(256) void k_knn_wave(int n_query,
                                                   const double* __restrict__ sy,
                                                   const double* __restrict__ sz, int k,
                                                   int exclude_self, int n_total, int last_level,
-                                                  int32_t* __restrict__ out_idx,
+                                                  int max_ring, int32_t* __restrict__ out_idx,
                                                   double* __restrict__ out_d2,
                                                   int32_t* __restrict__ fail_list,
                                                   int32_t* __restrict__ fail_count) {
@@ -280,63 +284,76 @@ __global__ __launch_bounds__(256) void k_knn_wave(int n_query,
   int tau_i = 0x7FFFFFFF;
   bool done = false;
   const int rmax_grid = max(g.nx, max(g.ny, g.nz));
-  for (int r = 0; r <= kMaxRing && !done; ++r) {
-    for (int dz = -r; dz <= r; ++dz) {
-      const int zz = cz + dz;
-      if (zz < 0 || zz >= g.nz) continue;
-      for (int dy = -r; dy <= r; ++dy) {
-        const int yy = cy + dy;
-        if (yy < 0 || yy >= g.ny) continue;
-        const int row = (zz * g.ny + yy) * g.nx;
+  for (int r = 0; r <= max_ring && !done; ++r) {
+    // The shell's row segments, 64 at a time: every lane looks one up (two loads), then the
+    // wave scans the non-empty ones together. Around an isolated point nearly all of them
+    // are empty, so a wide shell costs a few parallel lookups, not hundreds of serial ones.
+    const int w = 2 * r + 1;
+    const int nseg = 2 * w * w;  // two slots per row: [full row | -] or [left end | right end]
+    for (int sbase = 0; sbase < nseg; sbase += 64) {
+      const int sg = sbase + lane;
+      int qb_l = 0, qe_l = 0;
+      if (sg < nseg) {
+        const int ri = sg >> 1, part = sg & 1;
+        const int dz = ri / w - r, dy = ri % w - r;
+        const int zz = cz + dz, yy = cy + dy;
         const bool full = (dz == -r || dz == r || dy == -r || dy == r);
-        const int nseg = full ? 1 : (r > 0 ? 2 : 1);
-        for (int s = 0; s < nseg; ++s) {
-          int x0, x1;
-          if (full) {
+        int x0 = 0, x1 = -1;
+        if (full) {
+          if (part == 0) {
             x0 = cx - r;
             x1 = cx + r;
-          } else {
-            x0 = x1 = s == 0 ? cx - r : cx + r;
           }
-          x0 = x0 < 0 ? 0 : x0;
-          x1 = x1 >= g.nx ? g.nx - 1 : x1;
-          if (x0 > x1) continue;
-          const int qb = start[row + x0], qe = start[row + x1 + 1];
-          for (int base = qb; base < qe; base += 64) {
-            const int q = base + lane;
-            const bool valid = q < qe && !(exclude_self && q == p);
-            double d = __builtin_inf();
-            int id = 0x7FFFFFFF;
-            if (valid) {
-              d = sqdist3(x, y, z, sx[q], sy[q], sz[q]);
-              id = order[q];
+        } else if (r > 0) {
+          x0 = x1 = part == 0 ? cx - r : cx + r;
+        }
+        x0 = x0 < 0 ? 0 : x0;
+        x1 = x1 >= g.nx ? g.nx - 1 : x1;
+        if (zz >= 0 && zz < g.nz && yy >= 0 && yy < g.ny && x0 <= x1) {
+          const int row = (zz * g.ny + yy) * g.nx;
+          qb_l = start[row + x0];
+          qe_l = start[row + x1 + 1];
+        }
+      }
+      unsigned long long segs = __ballot(qe_l > qb_l);
+      while (segs) {
+        const int sl = __ffsll(segs) - 1;
+        segs &= segs - 1;
+        const int qb = __shfl(qb_l, sl, 64), qe = __shfl(qe_l, sl, 64);
+        for (int base = qb; base < qe; base += 64) {
+          const int q = base + lane;
+          const bool valid = q < qe && !(exclude_self && q == p);
+          double d = __builtin_inf();
+          int id = 0x7FFFFFFF;
+          if (valid) {
+            d = sqdist3(x, y, z, sx[q], sy[q], sz[q]);
+            id = order[q];
+          }
+          const bool cand = valid && (have < k || d < tau_d || (d == tau_d && id < tau_i));
+          unsigned long long mask = __ballot(cand);
+          while (mask) {
+            const int l = __ffsll(mask) - 1;
+            mask &= mask - 1;
+            const double nd = __shfl(d, l, 64);
+            const int ni = __shfl(id, l, 64);
+            if (have == k && !(nd < tau_d || (nd == tau_d && ni < tau_i))) continue;
+            const bool less = lane < have && (bd < nd || (bd == nd && bi < ni));
+            const int pos = __popcll(__ballot(less));
+            const double pd = __shfl_up(bd, 1, 64);
+            const int pi = __shfl_up(bi, 1, 64);
+            const int top = have < k ? have : k - 1;
+            if (lane > pos && lane <= top) {
+              bd = pd;
+              bi = pi;
             }
-            const bool cand = valid && (have < k || d < tau_d || (d == tau_d && id < tau_i));
-            unsigned long long mask = __ballot(cand);
-            while (mask) {
-              const int l = __ffsll(mask) - 1;
-              mask &= mask - 1;
-              const double nd = __shfl(d, l, 64);
-              const int ni = __shfl(id, l, 64);
-              if (have == k && !(nd < tau_d || (nd == tau_d && ni < tau_i))) continue;
-              const bool less = lane < have && (bd < nd || (bd == nd && bi < ni));
-              const int pos = __popcll(__ballot(less));
-              const double pd = __shfl_up(bd, 1, 64);
-              const int pi = __shfl_up(bi, 1, 64);
-              const int top = have < k ? have : k - 1;
-              if (lane > pos && lane <= top) {
-                bd = pd;
-                bi = pi;
-              }
-              if (lane == pos) {
-                bd = nd;
-                bi = ni;
-              }
-              if (have < k) ++have;
-              if (have == k) {
-                tau_d = __shfl(bd, k - 1, 64);
-                tau_i = __shfl(bi, k - 1, 64);
-              }
+            if (lane == pos) {
+              bd = nd;
+              bi = ni;
+            }
+            if (have < k) ++have;
+            if (have == k) {
+              tau_d = __shfl(bd, k - 1, 64);
+              tau_i = __shfl(bi, k - 1, 64);
             }
           }
         }
@@ -431,7 +448,8 @@ int knn_device(Ctx* c, const double* xyz, int64_t n, int32_t k, int32_t exclude_
   int n_query = N;
   const int32_t* list = nullptr;
   for (int level = 0;; ++level) {
-    const int last = (g.nx - 2 <= kMaxRing && g.ny - 2 <= kMaxRing && g.nz - 2 <= kMaxRing) ? 1 : 0;
+    const int ring = level >= 2 && k <= 64 ? kWideRing : kMaxRing;
+    const int last = (g.nx - 2 <= ring && g.ny - 2 <= ring && g.nz - 2 <= ring) ? 1 : 0;
     PQ_HIP(hipMemsetAsync(fail_count, 0, 4, c->stream));
     {
       ProfScope ps(c, level == 0 ? "knn_search" : "knn_retry");
@@ -449,7 +467,7 @@ int knn_device(Ctx* c, const double* xyz, int64_t n, int32_t k, int32_t exclude_
         KnnGrid kg{g.nx, g.ny, g.nz, g.cell};
         hipLaunchKernelGGL(k_knn_wave, dim3(ceil_div(n_query, 4)), dim3(256), 0, c->stream, n_query,
                            list, pos_of, kg, g.start, g.order, g.cell_of, g.sx, g.sy, g.sz, k,
-                           exclude_self, N, last, idx, d2, fl, fail_count);
+                           exclude_self, N, last, ring, idx, d2, fl, fail_count);
         PQ_HIP(hipGetLastError());
       } else if (k <= 48)
         PQ_TRY(launch_knn<256>(c, n_query, list, pos_of, g, k, exclude_self, N, last, idx, d2, fl,
