@@ -368,6 +368,14 @@ static void apply_op(Ctx* c, const System& S, const Work& w, const double* v, do
   }
 }
 
+// Plain launches instead of graph replays when asked to (PYQSM_NO_GRAPH) or when rocprofv3's
+// tool library is loaded: this ROCm's profiler crashes inside hipGraphLaunch of the
+// multigrid iteration graphs (kernel timings are unaffected by the switch).
+static bool graphs_enabled() {
+  static const bool on = !getenv("PYQSM_NO_GRAPH") && !getenv("ROCP_TOOL_LIBRARIES");
+  return on;
+}
+
 // A burst of kBurst CG iterations recorded once as a hipGraph and replayed: at a
 // few thousand points an iteration is four ~5 us launches, and replaying a graph
 // costs about a third of launching them one by one.
@@ -429,7 +437,7 @@ static int jacobi_pcg(Ctx* c, const System& S, const Work& w, const double* b, d
   int it = 0, best_it = 0;
   bool broke = false;
   hipGraphExec_t exec = nullptr;
-  if (getenv("PYQSM_NO_GRAPH")) cache = nullptr;
+  if (!graphs_enabled()) cache = nullptr;
   while (!done && it < max_it) {
     // bursts have an even length so that each one starts at parity 0
     int burst = std::min<int>(kBurst, max_it - it);
@@ -550,7 +558,7 @@ static int amg_pcg(Ctx* c, const System& S, const Work& w, AmgHierarchy* H, cons
     hipLaunchKernelGGL(k_direction, grid, block, 0, c->stream, N, w.z, w.dir, w.sc, par);
     return 0;
   };
-  if (getenv("PYQSM_NO_GRAPH")) cache = nullptr;  // plain launches (profilers that cannot follow graphs)
+  if (!graphs_enabled()) cache = nullptr;
   // graphs are keyed by (hierarchy, target vector, burst length)
   auto run_burst = [&](int len) -> int {
     hipGraphExec_t exec = nullptr;
