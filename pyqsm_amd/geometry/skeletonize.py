@@ -44,10 +44,15 @@ def point_cloud_laplacian(pts, mollify_factor=1e-5, n_neighbors=30, device: int 
     (indptr, indices, data), mass = hip.pc_laplacian(pts, n_neighbors, mollify_factor,
                                                      device=device)
     n = len(pts)
-    return csr_matrix((data, indices, indptr), shape=(n, n)), diags(mass)
+    L = csr_matrix((data, indices, indptr), shape=(n, n))
+    L.has_sorted_indices = True          # rows are written in column order (laplacian.hip: k_rows)
+    L._pyqsm_symmetric = True            # exactly symmetric by construction; spares a 60 ms check per solve
+    return L, diags(mass)
 
 
 def _is_symmetric(L) -> bool:
+    if getattr(L, "_pyqsm_symmetric", False):
+        return True
     d = (L - L.T)
     if d.nnz == 0:
         return True
