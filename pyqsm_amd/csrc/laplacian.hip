@@ -302,6 +302,7 @@ struct Entry {  // one off-diagonal contribution
 
 static constexpr double kDelaunayTol = 1e-10;
 static constexpr int kMaxFlipRounds = 2000;
+static constexpr int kFlipBatch = 8;  // rounds queued between two looks at the counters
 
 __device__ __host__ inline int nx3(int c) { return c == 2 ? 0 : c + 1; }
 __device__ __host__ inline int pv3(int c) { return c == 0 ? 2 : c - 1; }
@@ -479,33 +480,46 @@ __global__ __launch_bounds__(256) void k_flip_seed(int H, const double* __restri
 
 // Round part 1: every candidate of the list claims its two faces and their four outer
 // neighbours; the claim carries the round in its upper half, so claims never need clearing.
-__global__ __launch_bounds__(256) void k_flip_claim(int m, const int32_t* __restrict__ list,
+// Priority of a candidate within its round: a bijective hash of the half-edge id. With the id
+// itself, a strip of k adjacent candidates flips one per round (ids grow along the mesh):
+// ~450 rounds on a contracted 1 M-point cloud; hashed, the local maxima are spread out and
+// a strip clears in O(log k) rounds. The final triangulation does not depend on the order.
+__device__ __forceinline__ unsigned long long flip_priority(int h) {
+  return (unsigned long long)(unsigned(h + 1) * 0x9E3779B1u);
+}
+
+// (The list length lives on the device — the previous round's counter — and the kernels walk
+// the list with a grid stride, so several rounds are queued without a host round trip.)
+__global__ __launch_bounds__(256) void k_flip_claim(const int32_t* __restrict__ m_ptr,
+                                                    const int32_t* __restrict__ list,
                                                     unsigned long long stamp,
                                                     const double* __restrict__ fl,
                                                     const int32_t* __restrict__ fn,
                                                     unsigned long long* __restrict__ claim,
                                                     uint8_t* __restrict__ is_cand) {
-  int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= m) return;
-  const int h = list[i];
-  FlipInfo q;
-  const bool cand = flip_candidate(h, fl, fn, &q);
-  is_cand[i] = cand;
-  if (!cand) return;
-  const unsigned long long pr = stamp | (unsigned long long)(h + 1);
-  atomicMax(&claim[q.f], pr);
-  atomicMax(&claim[q.g], pr);
-  atomicMax(&claim[fn[3 * size_t(q.f) + nx3(q.c)] / 3], pr);
-  atomicMax(&claim[fn[3 * size_t(q.f) + pv3(q.c)] / 3], pr);
-  atomicMax(&claim[fn[3 * size_t(q.g) + nx3(q.d)] / 3], pr);
-  atomicMax(&claim[fn[3 * size_t(q.g) + pv3(q.d)] / 3], pr);
+  const int m = *m_ptr;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < m; i += gridDim.x * 256) {
+    const int h = list[i];
+    FlipInfo q;
+    const bool cand = flip_candidate(h, fl, fn, &q);
+    is_cand[i] = cand;
+    if (!cand) continue;
+    const unsigned long long pr = stamp | flip_priority(h);
+    atomicMax(&claim[q.f], pr);
+    atomicMax(&claim[q.g], pr);
+    atomicMax(&claim[fn[3 * size_t(q.f) + nx3(q.c)] / 3], pr);
+    atomicMax(&claim[fn[3 * size_t(q.f) + pv3(q.c)] / 3], pr);
+    atomicMax(&claim[fn[3 * size_t(q.g) + nx3(q.d)] / 3], pr);
+    atomicMax(&claim[fn[3 * size_t(q.g) + pv3(q.d)] / 3], pr);
+  }
 }
 
 // Round part 2: a candidate that owns all six faces flips its edge.
 //   before: f = (a, b, k) with edge c = a->b,   g = (b, a, l) with edge d = b->a
 //   after:  f = (a, l, k),  g = (b, k, l)       (new edge l->k in f, k->l in g)
 // A candidate that lost stays on the list; a flip puts its five edges on it.
-__global__ __launch_bounds__(256) void k_flip_apply(int m, const int32_t* __restrict__ list,
+__global__ __launch_bounds__(256) void k_flip_apply(const int32_t* __restrict__ m_ptr,
+                                                    const int32_t* __restrict__ list,
                                                     const uint8_t* __restrict__ is_cand,
                                                     unsigned long long stamp, int round_id,
                                                     int32_t* __restrict__ fv,
@@ -515,14 +529,17 @@ __global__ __launch_bounds__(256) void k_flip_apply(int m, const int32_t* __rest
                                                     int32_t* __restrict__ mark,
                                                     int32_t* __restrict__ next,
                                                     int32_t* __restrict__ counts /*[0] next size, [1] flips*/) {
-  int i = blockIdx.x * 256 + threadIdx.x;
+  const int m = *m_ptr;
+  // wave-uniform trip count: the appends below are wave-cooperative
+  for (int base = blockIdx.x * 256; base < m; base += gridDim.x * 256) {
+  const int i = base + threadIdx.x;
   int push[5];
   int np = 0;
   bool flipped = false;
   if (i < m && is_cand[i]) {
     const int h = list[i];
     const int f = h / 3, c = h % 3;
-    const unsigned long long pr = stamp | (unsigned long long)(h + 1);
+    const unsigned long long pr = stamp | flip_priority(h);
     // f and g first: while both are ours nobody else touches their links
     bool mine = claim[f] == pr;
     int g = 0, d = 0;
@@ -591,6 +608,7 @@ __global__ __launch_bounds__(256) void k_flip_apply(int m, const int32_t* __rest
   for (int p = 0; p < keep; ++p) next[slot++] = push[p];
   const unsigned long long fb = __ballot(flipped);
   if (fb != 0 && (threadIdx.x & 63) == 0) atomicAdd(counts + 1, __popcll(fb));
+  }
 }
 
 __global__ __launch_bounds__(256) void k_cover_vcount(int F, const int32_t* __restrict__ fv,
@@ -852,7 +870,7 @@ int pyqsm_pc_laplacian(const double* xyz, int64_t n, int32_t k, double moll, int
     PQ_TRY(c->arena.get(size_t(F) * 3 + 1, &d_list[0]));
     PQ_TRY(c->arena.get(size_t(F) * 3 + 1, &d_list[1]));
     PQ_TRY(c->arena.get(size_t(F) * 3 + 1, &d_iscand));
-    PQ_TRY(c->arena.get(2, &d_cnt));
+    PQ_TRY(c->arena.get(size_t(kMaxFlipRounds + 2) * 2, &d_cnt));
     PQ_HIP(hipMemsetAsync(d_vcount, 0, (size_t(n) + 1) * 4, c->stream));
     PQ_HIP(hipMemsetAsync(d_cursor, 0, size_t(n) * 4, c->stream));
     PQ_HIP(hipMemsetAsync(d_nnzrow, 0, (size_t(n) + 1) * 4, c->stream));
@@ -881,27 +899,33 @@ int pyqsm_pc_laplacian(const double* xyz, int64_t n, int32_t k, double moll, int
       ProfScope pf(c, "lap_flips");
       PQ_HIP(hipMemsetAsync(d_claim, 0, (size_t(F) + 1) * 8, c->stream));
       PQ_HIP(hipMemsetAsync(d_mark, 0, (size_t(F) * 3 + 1) * 4, c->stream));
-      PQ_HIP(hipMemsetAsync(d_cnt, 0, 8, c->stream));
+      // counters: slot 0 = seeding pass, slot r + 1 = round r: {next list length, flips}
+      PQ_HIP(hipMemsetAsync(d_cnt, 0, size_t(kMaxFlipRounds + 2) * 8, c->stream));
       hipLaunchKernelGGL(k_flip_seed, gh, blk, 0, c->stream, 3 * F, d_fl, d_fn, d_list[0], d_cnt);
       int32_t hc[2] = {0, 0};
       PQ_HIP(hipMemcpyAsync(hc, d_cnt, 8, hipMemcpyDeviceToHost, c->stream));
       PQ_HIP(hipStreamSynchronize(c->stream));
-      int m = hc[0];
-      for (int round = 0; round < kMaxFlipRounds && m > 0; ++round) {
-        const int32_t* cur = d_list[round & 1];
-        int32_t* nxt = d_list[(round & 1) ^ 1];
-        const unsigned long long stamp = (unsigned long long)(round + 1) << 32;
-        const dim3 gm(ceil_div(m, 256));
-        PQ_HIP(hipMemsetAsync(d_cnt, 0, 8, c->stream));
-        hipLaunchKernelGGL(k_flip_claim, gm, blk, 0, c->stream, m, cur, stamp, d_fl, d_fn, d_claim,
-                           d_iscand);
-        hipLaunchKernelGGL(k_flip_apply, gm, blk, 0, c->stream, m, cur, d_iscand, stamp, round, d_fv,
-                           d_fl, d_fn, d_claim, d_mark, nxt, d_cnt);
+      int m = hc[0];  // last list length the host has seen (sizes the next launches)
+      for (int round = 0; round < kMaxFlipRounds && m > 0;) {
+        // a batch of rounds between two looks at the counters; the lists shrink fast, and a
+        // kernel whose list is longer than its grid covers simply strides
+        const dim3 gm(unsigned(std::min<int64_t>(ceil_div(m, 256), 4096)));
+        const int batch_end = std::min(round + kFlipBatch, kMaxFlipRounds);
+        for (; round < batch_end; ++round) {
+          const int32_t* cur = d_list[round & 1];
+          int32_t* nxt = d_list[(round & 1) ^ 1];
+          const unsigned long long stamp = (unsigned long long)(round + 1) << 32;
+          hipLaunchKernelGGL(k_flip_claim, gm, blk, 0, c->stream, d_cnt + 2 * round, cur, stamp, d_fl,
+                             d_fn, d_claim, d_iscand);
+          hipLaunchKernelGGL(k_flip_apply, gm, blk, 0, c->stream, d_cnt + 2 * round, cur, d_iscand, stamp,
+                             round, d_fv, d_fl, d_fn, d_claim, d_mark, nxt, d_cnt + 2 * (round + 1));
+        }
         PQ_HIP(hipGetLastError());
-        PQ_HIP(hipMemcpyAsync(hc, d_cnt, 8, hipMemcpyDeviceToHost, c->stream));
+        PQ_HIP(hipMemcpyAsync(hc, d_cnt + 2 * round, 8, hipMemcpyDeviceToHost, c->stream));
         PQ_HIP(hipStreamSynchronize(c->stream));
-        if (hc[1] == 0) break;  // nothing could be flipped
+        if (hc[1] == 0) break;  // the last round of the batch flipped nothing: done (or stuck)
         m = hc[0];
+        if (getenv("PYQSM_LBC_TRACE")) fprintf(stderr, "flip round %d list %d flips(last) %d\n", round, hc[0], hc[1]);
       }
       hipLaunchKernelGGL(k_cover_vcount, gf, blk, 0, c->stream, F, d_fv, d_vcount);
     }
