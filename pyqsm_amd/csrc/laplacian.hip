@@ -656,6 +656,56 @@ __device__ __forceinline__ bool ent_less(const Entry& a, const Entry& b) {
   return a.col < b.col || (a.col == b.col && a.key < b.key);
 }
 
+// Rank sort of one row by the wave with PER entries per lane (rows of up to 64 * PER
+// entries). (col, key) is compared as ONE 64-bit integer; equal pairs (both ends of a loop
+// edge of the flipped cover) keep their input order, so ranks stay a permutation.
+template <int PER>
+__device__ __forceinline__ void sort_row_wave(int i, int b, int m, int lane, Entry* __restrict__ ent,
+                                              int32_t* __restrict__ nnz_row) {
+  unsigned long long ck[PER];
+  double val[PER];
+  int rank[PER];
+  bool first[PER];
+#pragma unroll
+  for (int t = 0; t < PER; ++t) {
+    const int idx = lane + 64 * t;
+    ck[t] = ~0ull;
+    val[t] = 0.0;
+    rank[t] = 0;
+    first[t] = true;
+    if (idx < m) {
+      const Entry x = ent[b + idx];
+      ck[t] = ((unsigned long long)(unsigned)x.col << 32) | (unsigned)x.key;
+      val[t] = x.val;
+    }
+  }
+#pragma unroll
+  for (int cj = 0; cj < PER; ++cj) {
+    const int cnt = min(64, m - 64 * cj);  // <= 0 for chunks beyond the row
+    for (int l = 0; l < cnt; ++l) {
+      const unsigned lo = __builtin_amdgcn_readlane(unsigned(ck[cj]), l);
+      const unsigned hi = __builtin_amdgcn_readlane(unsigned(ck[cj] >> 32), l);
+      const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+      const int src = 64 * cj + l;
+#pragma unroll
+      for (int t = 0; t < PER; ++t) {
+        const bool less = o < ck[t] || (o == ck[t] && src < lane + 64 * t);
+        rank[t] += less ? 1 : 0;
+        if (less && hi == unsigned(ck[t] >> 32)) first[t] = false;
+      }
+    }
+  }
+  int distinct = 0;
+#pragma unroll
+  for (int t = 0; t < PER; ++t) {
+    const bool valid = lane + 64 * t < m;
+    const int col = int(unsigned(ck[t] >> 32));
+    if (valid) ent[b + rank[t]] = Entry{col, int(unsigned(ck[t])), val[t]};
+    distinct += __popcll(__ballot(valid && first[t] && col != i));
+  }
+  if (lane == 0) nnz_row[i] = distinct + 1;  // + diagonal (loop edges i-i carry no weight)
+}
+
 // Sort the contributions of every row by (col, key) and count its distinct columns:
 // one wave per row, rank sort in registers (lane l holds entries l, l+64, ...; every
 // entry is broadcast once and compared by all lanes), so a 70-entry row costs ~70
@@ -687,56 +737,10 @@ __global__ __launch_bounds__(256) void k_sort_rows(int n, const int32_t* __restr
     }
     return;
   }
-  const int chunks = (m + 63) >> 6;
-  int col[kSortPer], key[kSortPer], rank[kSortPer];
-  double val[kSortPer];
-  bool first[kSortPer];
-#pragma unroll
-  for (int t = 0; t < kSortPer; ++t) {
-    const int idx = lane + 64 * t;
-    col[t] = 0x7FFFFFFF;
-    key[t] = 0x7FFFFFFF;
-    val[t] = 0.0;
-    rank[t] = 0;
-    first[t] = true;
-    if (t < chunks && idx < m) {
-      const Entry x = ent[b + idx];
-      col[t] = x.col;
-      key[t] = x.key;
-      val[t] = x.val;
-    }
-  }
-#pragma unroll
-  for (int cj = 0; cj < kSortPer; ++cj) {
-    if (cj < chunks) {
-      const int cnt = min(64, m - 64 * cj);
-      for (int l = 0; l < cnt; ++l) {
-        const int oc = __builtin_amdgcn_readlane(col[cj], l);
-        const int ok = __builtin_amdgcn_readlane(key[cj], l);
-#pragma unroll
-        for (int t = 0; t < kSortPer; ++t) {
-          if (t < chunks) {
-            // (col, key) can repeat (both ends of a loop edge of the flipped cover): ties
-            // keep their input order, so ranks stay a permutation
-            const bool same = oc == col[t];
-            const bool less = oc < col[t] || (same && (ok < key[t] || (ok == key[t] && 64 * cj + l < lane + 64 * t)));
-            rank[t] += less ? 1 : 0;
-            if (same && less) first[t] = false;
-          }
-        }
-      }
-    }
-  }
-  int distinct = 0;
-#pragma unroll
-  for (int t = 0; t < kSortPer; ++t) {
-    if (t < chunks) {
-      const bool valid = lane + 64 * t < m;
-      if (valid) ent[b + rank[t]] = Entry{col[t], key[t], val[t]};
-      distinct += __popcll(__ballot(valid && first[t] && col[t] != i));
-    }
-  }
-  if (lane == 0) nnz_row[i] = distinct + 1;  // + diagonal (loop edges i-i carry no weight)
+  // the usual row has 60-160 entries: no per-slot guards for it
+  if (m <= 128) sort_row_wave<2>(i, b, m, lane, ent, nnz_row);
+  else if (m <= 192) sort_row_wave<3>(i, b, m, lane, ent, nnz_row);
+  else sort_row_wave<kSortPer>(i, b, m, lane, ent, nnz_row);
 }
 
 // Per row (sorted by k_sort_rows): the merged row with its diagonal, and the lumped mass.
@@ -934,6 +938,20 @@ int pyqsm_pc_laplacian(const double* xyz, int64_t n, int32_t k, double moll, int
       hipLaunchKernelGGL(k_cover_weights, gf, blk, 0, c->stream, F, d_fv, d_fl, d_vcount, d_cursor,
                          d_ent, d_area);
       PQ_HIP(hipGetLastError());
+    }
+    if (getenv("PYQSM_LBC_TRACE")) {  // longest row of contributions
+      std::vector<int32_t> rs(size_t(n) + 1);
+      PQ_HIP(hipMemcpyAsync(rs.data(), d_vcount, (size_t(n) + 1) * 4, hipMemcpyDeviceToHost, c->stream));
+      PQ_HIP(hipStreamSynchronize(c->stream));
+      int mx = 0;
+      int64_t over = 0;
+      for (int64_t i = 0; i < n; ++i) {
+        const int len = rs[size_t(i) + 1] - rs[size_t(i)];
+        mx = std::max(mx, len);
+        over += len > 64 * kSortPer;
+      }
+      fprintf(stderr, "laplacian rows: %d contributions at most, %lld rows beyond the wave path\n", mx,
+              (long long)over);
     }
     hipLaunchKernelGGL(k_sort_rows, dim3(ceil_div(n, 4)), blk, 0, c->stream, N, d_vcount, d_ent,
                        d_nnzrow);
