@@ -5,8 +5,8 @@ out = "profiles"
 # 1. kernel stats of the bench command
 rows = list(csv.DictReader(open("gpurun_out/prof_final/bench_kernel_stats.csv")))
 with open(f"{out}/{ROUND}_bench_kernel_stats_final.csv", "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-skeleton  (round 1, end of round;\n")
-    f.write("# the skeleton section replays hipGraphs, which this rocprofv3 build cannot follow: profiled separately with PYQSM_NO_GRAPH=1)\n")
+    f.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py  (round 1, end of round; under the\n")
+    f.write("# profiler the multigrid iterations are launched kernel by kernel instead of replayed as hipGraphs: lbc.hip graphs_enabled())\n")
     f.write("kernel,calls,avg_us,total_ms,percent\n")
     for r in rows:
         f.write('"%s",%s,%.2f,%.3f,%s\n' % (r["Name"].split("(")[0], r["Calls"], float(r["AverageNs"]) / 1e3,
