@@ -41,21 +41,6 @@ __device__ __forceinline__ double sqdist(double ax, double ay, double az, double
       }                                                            \
     }
 
-__global__ __launch_bounds__(256) void k_core(int n, Stencil st, const int32_t* __restrict__ start,
-                                              const int32_t* __restrict__ cell_of,
-                                              const double* __restrict__ sx,
-                                              const double* __restrict__ sy,
-                                              const double* __restrict__ sz, double r2,
-                                              int min_pts, uint8_t* __restrict__ core) {
-  int p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= n) return;
-  const double x = sx[p], y = sy[p], z = sz[p];
-  const int c = cell_of[p];
-  int cnt = 0;
-  FOR_STENCIL(c, st, start, q, { cnt += sqdist(x, y, z, sx[q], sy[q], sz[q]) <= r2; })
-  core[p] = cnt >= min_pts;
-}
-
 struct TileLds {
   double x[4][64], y[4][64], z[4][64];  // the current chunk of candidates, per wave
 };

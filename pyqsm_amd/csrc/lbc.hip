@@ -107,34 +107,6 @@ __global__ __launch_bounds__(256) void k_init(int n, const double* __restrict__ 
   reduce3_atomic(bb[0], bb[1], bb[2], sc->bb);
 }
 
-// OP_A: q = wl .* t + wh^2 .* v   (t = L(L(wl .* v)))
-// OP_B: q = c * t + wh .* v       (t = L v)
-// and, when sc is given, pq += v . q
-template <int OP>
-__global__ __launch_bounds__(256) void k_apply_tail(int n, const double* __restrict__ t,
-                                                    const double* __restrict__ wl, double c,
-                                                    const double* __restrict__ wh,
-                                                    const double* __restrict__ v,
-                                                    double* __restrict__ q,
-                                                    Scal* __restrict__ sc, int par) {
-  int i = blockIdx.x * 256 + threadIdx.x;
-  double pq[3] = {0, 0, 0};
-  if (sc && i < 3) sc->rz[par ^ 1][i] = 0.0;  // k_update of this iteration accumulates there
-  if (i < n) {
-    const double a = OP == OP_A ? wl[i] : c;
-    const double h = OP == OP_A ? wh[i] * wh[i] : wh[i];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const double d = v[3 * i + k];
-      const double qi = a * t[3 * i + k] + h * d;
-      q[3 * i + k] = qi;
-      pq[k] = d * qi;
-    }
-  }
-  if (sc) reduce3_atomic(pq[0], pq[1], pq[2], sc->pq[par]);
-}
-
-
 // Sparse pass fused with the operator tail: t = L v for row i, then
 //   OP_A: q_i = wl_i * t + wh_i^2 * v_i    (v here is L(wl .* dir), `dirv` the CG direction)
 //   OP_B: q_i = c * t + wh_i * v_i
