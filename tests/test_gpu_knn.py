@@ -54,3 +54,28 @@ def test_outliers_far_from_everything(gpu):
     idx, d2 = hip.knn(P, 10, True, device=gpu)
     idx0, d20 = oracle.knn(P, 10, True)
     assert np.array_equal(d2, d20) and np.array_equal(idx, idx0)
+
+
+def test_randomised_differential(gpu):
+    """k on both sides of every register-list width (8/16/24/32) and beyond, with and without
+    the query itself, on uniform / clustered / lattice (many exact ties) / planar clouds."""
+    rng = np.random.default_rng(31)
+    ks = [1, 2, 7, 8, 9, 16, 17, 20, 24, 25, 31, 32, 33, 48]
+    for case, k in enumerate(ks * 2):
+        n = int(rng.integers(k + 2, 6000))
+        kind = case % 4
+        if kind == 0:
+            P = rng.uniform(0, 1, (n, 3))
+        elif kind == 1:
+            c = rng.uniform(0, 1, (5, 3))
+            P = c[rng.integers(0, 5, n)] + rng.normal(0, 1, (n, 3)) * rng.choice([0.003, 0.03, 0.2], (n, 1))
+        elif kind == 2:
+            P = rng.integers(0, 9, (n, 3)) * 0.125          # duplicates and equidistant neighbours
+        else:
+            P = rng.uniform(0, 1, (n, 3)) * [1, 1, 0]
+        P = P.astype(np.float32).astype(np.float64)
+        excl = bool(case % 2)
+        idx, d2 = hip.knn(P, k, excl, device=gpu)
+        idx0, d20 = oracle.knn(P, k, excl)
+        assert np.array_equal(d2, d20), (case, n, k, excl)
+        assert np.array_equal(idx, idx0), (case, n, k, excl)
