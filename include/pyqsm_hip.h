@@ -109,6 +109,18 @@ int pyqsm_list_intersections(const float* verts, int64_t V, const int32_t* tris,
                              uint32_t* ray_ids, uint32_t* prim_ids, float* t, float* uv,
                              int64_t hits_cap, int64_t* n_hits, int32_t device);
 
+/*
+ * Unsigned distance from query points to the mesh and the index of the closest
+ * triangle — open3d RaycastingScene.compute_distance, which `mri`
+ * (pyQSM/viz/ray_casting.py:237-260) reaches through compute_signed_distance; the sign
+ * is the occupancy of pyqsm_list_intersections (inside = negative), applied by the
+ * wrapper. Brute force, fp32; lowest triangle index on ties; T = 0 gives +inf.
+ *   qry f32 [Q,3]; dist f32 [Q]; prim u32 [Q].
+ */
+int pyqsm_point_mesh_distance(const float* verts, int64_t V, const int32_t* tris, int64_t T,
+                              const float* qry, int64_t Q, float* dist, uint32_t* prim,
+                              int32_t device);
+
 /* ---- eps-neighbourhood clustering (DBSCAN) ---------------------------- */
 /*
  * Stands in for sklearn.cluster.DBSCAN(eps, min_samples).fit(points) at

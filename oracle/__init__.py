@@ -56,6 +56,7 @@ def _lib():
         lib.orc_pc_laplacian.argtypes = [p, i64, i32, dbl, ctypes.POINTER(i64),
                                          ctypes.POINTER(p), ctypes.POINTER(p), ctypes.POINTER(p), p]
         lib.orc_free.restype = None
+        lib.orc_point_mesh_distance.argtypes = [p, i64, p, i64, p, i64, p, p]
         lib.orc_free.argtypes = [p]
         _LIB = lib
     return _LIB
@@ -135,6 +136,18 @@ def cast_rays(verts, tris, rays):
     if rc != 0:
         raise MemoryError("orc_cast_rays")
     return t_hit, prim, uv
+
+
+def point_mesh_distance(verts, tris, queries):
+    """(dist f32 [Q], prim u32 [Q]): unsigned distance to the mesh, closest triangle."""
+    v = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 3)
+    t = np.ascontiguousarray(tris, dtype=np.int32).reshape(-1, 3)
+    q = np.ascontiguousarray(queries, dtype=np.float32).reshape(-1, 3)
+    dist = np.empty(q.shape[0], dtype=np.float32)
+    prim = np.empty(q.shape[0], dtype=np.uint32)
+    _lib().orc_point_mesh_distance(_ptr(v), v.shape[0], _ptr(t), t.shape[0], _ptr(q), q.shape[0],
+                                   _ptr(dist), _ptr(prim))
+    return dist, prim
 
 
 def list_intersections(verts, tris, rays):

@@ -896,3 +896,82 @@ int orc_pc_laplacian(const double* xyz, int64_t n, int32_t k, double moll, int64
 }
 
 void orc_free(void* p) { free(p); }
+
+/* --------------------------------------------------------------------------
+ * orc_point_mesh_distance — unsigned distance from query points to a triangle mesh and
+ * the closest triangle (lowest index on ties), standing in for Open3D's
+ * RaycastingScene.compute_distance behind `mri` (pyQSM/viz/ray_casting.py:237-260;
+ * Open3D itself is not installable here: PARITY UNPINNED, pinned to analytic cases in
+ * tests/). Ericson's closest-point-on-triangle region walk in fp32, products rounded
+ * separately, in the operation order of pyqsm_amd/csrc/meshdist.hip. */
+static float orc_dot3f(float ax, float ay, float az, float bx, float by, float bz) {
+  float d = ax * bx;
+  d = d + ay * by;
+  d = d + az * bz;
+  return d;
+}
+
+int orc_point_mesh_distance(const float* verts, int64_t V, const int32_t* tris, int64_t T,
+                            const float* qry, int64_t Q, float* dist, uint32_t* prim) {
+  (void)V;
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < Q; ++i) {
+    const float px = qry[3 * i], py = qry[3 * i + 1], pz = qry[3 * i + 2];
+    float best = INFINITY;
+    uint32_t bp = 0xFFFFFFFFu;
+    for (int64_t j = 0; j < T; ++j) {
+      const float* a = verts + 3 * (int64_t)tris[3 * j];
+      const float* b = verts + 3 * (int64_t)tris[3 * j + 1];
+      const float* c = verts + 3 * (int64_t)tris[3 * j + 2];
+      const float ax = a[0], ay = a[1], az = a[2];
+      const float abx = b[0] - ax, aby = b[1] - ay, abz = b[2] - az;
+      const float acx = c[0] - ax, acy = c[1] - ay, acz = c[2] - az;
+      const float apx = px - ax, apy = py - ay, apz = pz - az;
+      const float d1 = orc_dot3f(abx, aby, abz, apx, apy, apz);
+      const float d2 = orc_dot3f(acx, acy, acz, apx, apy, apz);
+      float cx, cy, cz;
+      const float bpx = apx - abx, bpy = apy - aby, bpz = apz - abz;
+      const float d3 = orc_dot3f(abx, aby, abz, bpx, bpy, bpz);
+      const float d4 = orc_dot3f(acx, acy, acz, bpx, bpy, bpz);
+      const float cpx = apx - acx, cpy = apy - acy, cpz = apz - acz;
+      const float d5 = orc_dot3f(abx, aby, abz, cpx, cpy, cpz);
+      const float d6 = orc_dot3f(acx, acy, acz, cpx, cpy, cpz);
+      const float vc = d1 * d4 - d3 * d2;
+      const float vb = d5 * d2 - d1 * d6;
+      const float va = d3 * d6 - d5 * d4;
+      if (d1 <= 0.f && d2 <= 0.f) {
+        cx = cy = cz = 0.f;
+      } else if (d3 >= 0.f && d4 <= d3) {
+        cx = abx; cy = aby; cz = abz;
+      } else if (vc <= 0.f && d1 >= 0.f && d3 <= 0.f) {
+        const float v = d1 / (d1 - d3);
+        cx = v * abx; cy = v * aby; cz = v * abz;
+      } else if (d6 >= 0.f && d5 <= d6) {
+        cx = acx; cy = acy; cz = acz;
+      } else if (vb <= 0.f && d2 >= 0.f && d6 <= 0.f) {
+        const float w = d2 / (d2 - d6);
+        cx = w * acx; cy = w * acy; cz = w * acz;
+      } else if (va <= 0.f && (d4 - d3) >= 0.f && (d5 - d6) >= 0.f) {
+        const float w = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+        cx = abx + w * (acx - abx);
+        cy = aby + w * (acy - aby);
+        cz = abz + w * (acz - abz);
+      } else {
+        const float denom = 1.f / (va + vb + vc);
+        const float v = vb * denom, w = vc * denom;
+        cx = abx * v + acx * w;
+        cy = aby * v + acy * w;
+        cz = abz * v + acz * w;
+      }
+      const float ex = apx - cx, ey = apy - cy, ez = apz - cz;
+      const float d = orc_dot3f(ex, ey, ez, ex, ey, ez);
+      if (d < best) {
+        best = d;
+        bp = (uint32_t)j;
+      }
+    }
+    dist[i] = sqrtf(best);
+    prim[i] = bp;
+  }
+  return 0;
+}

@@ -37,6 +37,7 @@ SIGNATURES = {
     "pyqsm_cast_rays_dev": (ctypes.c_int, [vp, i64, vp, i64, vp, vp, vp, i32]),
     "pyqsm_list_intersections": (ctypes.c_int, [vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, vp,
                                                 i64, ctypes.POINTER(i64), i32]),
+    "pyqsm_point_mesh_distance": (ctypes.c_int, [vp, i64, vp, i64, vp, i64, vp, vp, i32]),
     "pyqsm_dbscan": (ctypes.c_int, [vp, i64, dbl, i32, vp, vp, i32]),
     "pyqsm_dbscan_dev": (ctypes.c_int, [vp, i64, dbl, i32, vp, vp, ctypes.POINTER(i64), i32]),
     "pyqsm_knn": (ctypes.c_int, [vp, i64, i32, i32, vp, vp, i32]),

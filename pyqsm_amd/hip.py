@@ -141,6 +141,17 @@ def list_intersections(verts, tris, rays, device: int = 0):
             "counts": counts}
 
 
+def point_mesh_distance(verts, tris, queries, device: int = 0):
+    """(dist f32 [Q], prim u32 [Q]): unsigned distance to the mesh and the closest triangle."""
+    v, t = _mesh(verts, tris)
+    q = np.ascontiguousarray(queries, dtype=np.float32).reshape(-1, 3)
+    dist = np.empty(q.shape[0], dtype=np.float32)
+    prim = np.empty(q.shape[0], dtype=np.uint32)
+    check(_lib.load().pyqsm_point_mesh_distance(_p(v), v.shape[0], _p(t), t.shape[0], _p(q), q.shape[0],
+                                                _p(dist), _p(prim), int(device)))
+    return dist, prim
+
+
 class DeviceMesh:
     """A mesh expanded into the sweep's 48-byte records, resident in HBM."""
 

@@ -7,7 +7,8 @@ on the HIP sweep instead of Open3D's RaycastingScene (Embree).
     get_points_inside_mesh(...)                       :53-71   (occupancy)
     create_rays_pinhole(...)       the RaycastingScene static the reference calls
     RaycastingScene                a small class with add_triangles / cast_rays /
-                                   list_intersections / compute_occupancy
+                                   list_intersections / compute_occupancy /
+                                   compute_distance / compute_signed_distance
 
 Meshes may be ``(vertices, triangles)`` tuples, objects with ``.vertices`` /
 ``.triangles`` (Open3D legacy layout) or with ``.vertex['positions']`` /
@@ -115,6 +116,42 @@ class RaycastingScene:
                               axis=1)
         counts = self.count_intersections(rays)
         return (counts % 2).astype(np.float32).reshape(q.shape[:-1])
+
+    def compute_distance(self, query_points) -> np.ndarray:
+        """Unsigned distance to the surface, float32, shape of the input minus its last axis."""
+        q = np.ascontiguousarray(_np(query_points), dtype=np.float32)
+        dist, _ = hip.point_mesh_distance(self._verts, self._tris, q.reshape(-1, 3), device=self.device)
+        return dist.reshape(q.shape[:-1])
+
+    def compute_signed_distance(self, query_points) -> np.ndarray:
+        """Distance to the surface, negative inside a closed mesh (occupancy by crossing parity,
+        as ``compute_occupancy``); what ray_casting.py:250,256 asks of the scene."""
+        q = np.ascontiguousarray(_np(query_points), dtype=np.float32)
+        dist = self.compute_distance(q)
+        inside = self.compute_occupancy(q) > 0.5
+        return np.where(inside, -dist, dist).astype(np.float32)
+
+
+def mri(mesh=None, rcs_in=None, n_random: int = 256, grid: int = 64, device: int = 0):
+    """ray_casting.py:237-260: signed distances of ``n_random`` uniform random points in the
+    mesh's bounding box and of a ``grid``^3 lattice over it. The reference then shows 32
+    slices with matplotlib and stops in the debugger; this returns
+    ``(random_points, their signed distances, lattice points [g,g,g,3], signed distances [g,g,g])``
+    instead."""
+    if rcs_in is not None:
+        scene = rcs_in
+    elif mesh is not None:
+        scene = RaycastingScene(device)
+        scene.add_triangles(mesh)
+    else:
+        raise ValueError("No mesh or rcs provided for mri")
+    verts = scene._verts if mesh is None else mesh_arrays(mesh)[0]
+    min_bound, max_bound = verts.min(0), verts.max(0)
+    query_points = np.random.uniform(low=min_bound, high=max_bound, size=[n_random, 3]).astype(np.float32)
+    sd_random = scene.compute_signed_distance(query_points)
+    xyz_range = np.linspace(min_bound, max_bound, num=grid)
+    lattice = np.stack(np.meshgrid(*xyz_range.T), axis=-1).astype(np.float32)
+    return query_points, sd_random, lattice, scene.compute_signed_distance(lattice)
 
 
 def cast_rays(tmesh, surf_2d: bool = False, img: bool = False, pinhole_config=pinhole_config,

@@ -109,3 +109,21 @@ def test_numpy_operation_order_assumed_by_the_ransac_kernel():
     assert np.array_equal(c[:, 0], a[:, 1] * b[:, 2] - a[:, 2] * b[:, 1])
     assert np.array_equal(c[:, 1], a[:, 2] * b[:, 0] - a[:, 0] * b[:, 2])
     assert np.array_equal(c[:, 2], a[:, 0] * b[:, 1] - a[:, 1] * b[:, 0])
+
+
+def test_point_mesh_distance_known_answers():
+    """Cube: centre, above a face, off a corner, just inside, outside a face."""
+    v = np.array([[x, y, z] for x in (0, 1) for y in (0, 1) for z in (0, 1)], np.float32)
+    t = np.array([[0, 1, 3], [0, 3, 2], [4, 6, 7], [4, 7, 5], [0, 4, 5], [0, 5, 1], [2, 3, 7],
+                  [2, 7, 6], [0, 2, 6], [0, 6, 4], [1, 5, 7], [1, 7, 3]], np.int32)
+    q = np.array([[0.5, 0.5, 0.5], [0.5, 0.5, 2.0], [2, 2, 2], [0.5, 0.5, 0.875], [-1, 0.5, 0.5]],
+                 np.float32)
+    d, p = oracle.point_mesh_distance(v, t, q)
+    assert np.allclose(d, [0.5, 1.0, np.sqrt(3), 0.125, 1.0], rtol=1e-6)
+    assert p[4] in (0, 1) and p[1] in (10, 11)          # x = 0 face / z = 1 face
+    # a single triangle: region walk (vertex, edge, interior)
+    tv = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    tt = np.array([[0, 1, 2]], np.int32)
+    q = np.array([[-1, -1, 0], [0.5, -2, 0], [0.25, 0.25, 3], [2, 2, 0]], np.float32)
+    d, _ = oracle.point_mesh_distance(tv, tt, q)
+    assert np.allclose(d, [np.sqrt(2), 2.0, 3.0, np.sqrt(4.5)], rtol=1e-6)
