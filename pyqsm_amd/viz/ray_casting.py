@@ -203,6 +203,30 @@ def raycast_to_pcd(mesh, pinhole_config=pinhole_config, device: int = 0):
     return PointCloud(points), ans["t_hit"][hit]
 
 
+def birdseye(mesh):
+    """ray_casting.py:194-203: an eye position above the middle of the mesh's bounding box, half
+    its height above the top."""
+    v, _ = mesh_arrays(mesh)
+    ub, lb = v.max(0).astype(np.float64), v.min(0).astype(np.float64)
+    half_diff = (ub - lb) / 2
+    mid = ub - half_diff
+    return [float(mid[0]), float(mid[1]), float(ub[2] + half_diff[2])]
+
+
+def project_to_image(mesh, pinhole_config=pinhole_config, device: int = 0):
+    """ray_casting.py:205-235: the pinhole view of the mesh. Returns ``(pcd, depth)``: the hit
+    points as a cloud and the ``t_hit`` image float32 [height, width] (+inf where nothing is
+    hit) that the reference shows with ``plt.imshow`` before stopping in the debugger."""
+    scene = RaycastingScene(device)
+    scene.add_triangles(mesh)
+    rays = create_rays_pinhole(**pinhole_config)
+    ans = scene.cast_rays(rays)
+    hit = np.isfinite(ans["t_hit"])
+    hits = rays[hit]
+    points = hits[:, :3] + hits[:, 3:] * ans["t_hit"][hit].reshape((-1, 1))   # :226
+    return PointCloud(points), ans["t_hit"]
+
+
 def sparse_cast_w_intersections(mesh, num: int = 10, device: int = 0):
     """ray_casting.py:151-192: a num x num grid of +z rays from below the bounding
     box; returns (ray segments [n,2,3], intersection points [m,3]) — every crossing,

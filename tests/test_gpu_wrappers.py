@@ -103,6 +103,22 @@ def test_sparse_cast_and_occupancy(gpu):
     assert set(zs) <= {0.0, 1.0} and len(zs) >= 8                        # bottom and top faces
 
 
+def test_project_to_image_and_birdseye(gpu):
+    verts, tris = synth.canopy_mesh(3000, seed=9, side=0.5)
+    eye = rc.birdseye((verts, tris))
+    assert eye[2] > verts[:, 2].max() and abs(eye[0] - 0.5 * (verts[:, 0].min() + verts[:, 0].max())) < 1e-5
+    cfg = {"fov_deg": 70, "center": list(0.5 * (verts.min(0) + verts.max(0))), "eye": eye, "up": [0, 1, 0],
+           "width_px": 160, "height_px": 120}
+    pcd, depth = rc.project_to_image((verts, tris), cfg)
+    assert depth.shape == (120, 160) and np.isfinite(depth).sum() == len(pcd.points) > 100
+    rays = rc.create_rays_pinhole(**cfg).reshape(-1, 6)
+    t0, _, _ = oracle.cast_rays(verts, tris, rays)
+    assert np.array_equal(depth.reshape(-1), t0)
+    # every hit point lies on the mesh: distance to it ~ 0
+    d, _ = oracle.point_mesh_distance(verts, tris, pcd.points.astype(np.float32))
+    assert d.max() < 1e-4
+
+
 def test_flat_imports_run_on_the_gpu(gpu):
     code = ("import numpy as np\n"
             "from math_utils.fit import cluster_DBSCAN\n"
