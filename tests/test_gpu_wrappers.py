@@ -103,6 +103,21 @@ def test_sparse_cast_and_occupancy(gpu):
     assert set(zs) <= {0.0, 1.0} and len(zs) >= 8                        # bottom and top faces
 
 
+def test_fit_cyl_to_cluster(gpu):
+    """qsm_generation.py:138-179 around fit_shape_RANSAC: good fit -> sampled cylinder + details;
+    a radius far above the previous one -> rejected."""
+    from pyqsm_amd.qsm_generation import fit_cyl_to_cluster
+    pts = synth.ring_cluster(4000, radius=0.3, seed=4)
+    cyls, details = [], []
+    ok = fit_cyl_to_cluster(None, pts, 0.28, np.arange(len(pts)), cyls, details, seed=5)
+    assert ok and len(cyls) == 1 and len(cyls[0].points) == 500
+    assert abs(details[0]["radius"] - 0.3) < 0.01 and details[0]["height"] == pts[:, 2].min()
+    assert np.allclose(details[0]["center"], pts.mean(0))
+    cyls2, details2 = [], []
+    assert not fit_cyl_to_cluster(None, pts, 0.05, np.arange(len(pts)), cyls2, details2, seed=5)
+    assert cyls2 == [] and details2 == []
+
+
 def test_project_to_image_and_birdseye(gpu):
     verts, tris = synth.canopy_mesh(3000, seed=9, side=0.5)
     eye = rc.birdseye((verts, tris))
