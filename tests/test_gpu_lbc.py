@@ -64,3 +64,38 @@ def test_max_it_reports_no_convergence(gpu):
     x, iters, resid, ok = hip.lbc_solve(L, g["wl"], g["wh"], g["points"], rtol=1e-14, max_it=25,
                                         device=gpu)
     assert not ok and 25 <= iters <= 30 and np.all(np.isfinite(x))
+
+
+def _small_system(n=1500, seed=3):
+    from pyqsm_amd import synth
+    P = synth.forest(n, seed=seed)
+    L, M = oracle.point_cloud_laplacian(P, 12, 1e-6)
+    return P, L.tocsr(), np.asarray(M)
+
+
+@pytest.mark.parametrize("path_env", [{}, {"PYQSM_AMG": "0"}, {"PYQSM_LBC_SORT": "0"}, {"PYQSM_NO_GRAPH": "1"}])
+def test_solver_variants_agree_with_spsolve(gpu, monkeypatch, path_env):
+    """Multigrid (default), Jacobi-PCG B-solves, unsorted unknowns, plain launches: every variant
+    must reproduce the SciPy direct solve of the same system to the parity bound."""
+    for k, v in path_env.items():
+        monkeypatch.setenv(k, v)
+    P, L, M = _small_system(6000)
+    wl = np.full(len(P), 3e3 * np.sqrt(M.mean()))
+    rng = np.random.default_rng(0)
+    wh = 3.0 * np.sqrt(M.mean() / M) ** rng.uniform(0.5, 1.5, len(P))     # rough positional weights
+    x, iters, resid, ok = hip.lbc_solve(L, wl, wh, P, rtol=1e-9, max_it=500000, device=gpu)
+    ref = oracle.least_squares_sparse(P, L, wl, wh)
+    assert ok, (iters, resid)
+    assert np.abs(x - ref).max() <= RTOL * np.abs(ref).max()
+
+
+def test_non_uniform_laplacian_weights_take_the_general_path(gpu):
+    """extract_skeleton never produces per-point wl, least_squares_sparse accepts them
+    (skeletonize.py:160-164): Jacobi-PCG on A itself, residual-based stop."""
+    P, L, M = _small_system(1200)
+    rng = np.random.default_rng(1)
+    wl = rng.uniform(0.5, 2.0, len(P))
+    wh = rng.uniform(1.0, 3.0, len(P))
+    x, iters, resid, ok = hip.lbc_solve(L, wl, wh, P, rtol=1e-11, max_it=400000, device=gpu)
+    ref = oracle.least_squares_sparse(P, L, wl, wh)
+    assert np.abs(x - ref).max() <= RTOL * np.abs(ref).max()
