@@ -345,8 +345,7 @@ static void apply_op(Ctx* c, const System& S, const Work& w, const double* v, do
 // tool library is loaded: this ROCm's profiler crashes inside hipGraphLaunch of the
 // multigrid iteration graphs (kernel timings are unaffected by the switch).
 static bool graphs_enabled() {
-  static const bool on = !getenv("PYQSM_NO_GRAPH") && !getenv("ROCP_TOOL_LIBRARIES");
-  return on;
+  return !getenv("PYQSM_NO_GRAPH") && !getenv("ROCP_TOOL_LIBRARIES");
 }
 
 // A burst of kBurst CG iterations recorded once as a hipGraph and replayed: at a
