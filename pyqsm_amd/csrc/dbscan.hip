@@ -3,13 +3,17 @@
 // cluster_dbscan call sites (pyQSM/geometry/point_cloud_processing.py:185,209).
 //
 // Parallel formulation of the sequential reference:
-//   1. bin points into cells of edge >= eps (grid.hip)
+//   1. bin points into cells of edge eps, then by octant inside each cell (grid.hip)
 //   2. core(i)  <=> #{ j in 27-cell stencil : d2(i,j) <= eps^2 } >= min_pts
-//   3. union-find over core-core pairs within eps (lock-free hooking, larger
-//      root under smaller, agent-scope atomics)
+//      (wave tiles with an early exit; stragglers in a wave-per-point pass)
+//   3. connected components of the core points on the graph of octant sub-cells:
+//      a hook pass without union-find, path compression, then lock-free union-find
+//      (randomised linking, agent-scope atomics) for what is left; per-point
+//      union-find when the grid had to be coarsened
 //   4. cluster number = rank of the component's smallest ORIGINAL core index
 //      (what the index-order seeding of the sequential algorithm produces)
 //   5. border point -> smallest cluster number among its core neighbours
+//      (a wave per non-core point)
 // The distance predicate is evaluated in fp64 exactly as scikit-learn does:
 // d2 = ((dx*dx) + dy*dy) + dz*dz with separately rounded products, compared
 // with fl(eps*eps). The library is compiled with -ffp-contract=off.
