@@ -7,12 +7,14 @@
 // Method: points are counting-sorted into a uniform cell grid (grid.hip) whose
 // edge is tuned so that an occupied cell holds about k/3 points. One lane per
 // query walks Chebyshev shells of cells around its own cell (each shell row is
-// one contiguous run of the sorted arrays) and keeps the best k candidates in a
-// per-lane LDS column (element j of lane t at [j*T + t]: conflict-free). A
+// one contiguous run of the sorted arrays) and keeps the best k candidates sorted in
+// registers (k <= 32, k_knn_reg) or in a per-lane LDS column (element j of lane t at
+// [j*T + t]: conflict-free, k_knn). A
 // query is final once its k-th distance is no larger than the radius the
 // visited cube is known to cover. The few queries that are not final after
-// kMaxRing shells (isolated outliers) are retried on a 4x coarser grid, and so
-// on, until the grid is small enough for the rings to cover it entirely.
+// kMaxRing shells (isolated outliers) are retried, one wave per query, on 4x coarser
+// grids derived from the fine one (grid.hip: coarsen_grid) until the shells cover the
+// whole grid.
 //
 // (Measured alternative for level 0, MI355X, 1 M points, k = 20: a wave-tiled search like
 // dbscan.hip's k_core_tiled — 64 consecutive queries, candidates broadcast from LDS, the K

@@ -4,16 +4,19 @@
 // The reference stacks A = [L*W_L ; W_H], forms A'A and factorises it three
 // times with SuperLU (once per coordinate). Here the normal equations
 //     (W_L L' L W_L + W_H^2) x = W_H^2 p
-// are solved matrix-free by a Jacobi-preconditioned conjugate gradient that
-// carries the three coordinates through every sparse pass together (one read of
-// L serves x, y and z). L'L is never formed. L must be symmetric (it is: the
+// are solved matrix-free; the three coordinates ride every sparse pass together (one
+// read of L serves x, y and z). L'L is never formed. L must be symmetric (it is: the
 // point-cloud Laplacian is), so L' x is computed as L x.
 //
-// HBM traffic per CG iteration (fp64, CSR with 32-bit indices):
-//   2 sparse passes  = 2 * (12*nnz + 52*n) bytes      (SURVEY.md §8 d-roofline)
-//   vector updates   ~ 10 three-column streams = 240*n bytes
-// All scalars (alpha, beta, dot products) stay on the device; the host looks at
-// the residual only every `kCheckEvery` iterations.
+// Uniform W_L = c I (what extract_skeleton always passes): flexible CG on A preconditioned
+// by B^-2, B = c L + W_H, each B-solve a CG preconditioned by one aggregation-multigrid
+// cycle (amg.hip), on spatially sorted unknowns — see lbc_solve_core / lbc_solve_device
+// below and DESIGN.md section 6. Per-point W_L: Jacobi-preconditioned CG on A.
+//
+// HBM traffic of one sparse pass (fp64, CSR with 32-bit indices): 12*nnz + 52*n bytes
+// (SURVEY.md §8 d-roofline); the scalars of the inner CGs (alpha, beta, dot products) stay
+// on the device, iterations are replayed as hipGraphs, and the host looks at a residual
+// only between replays.
 #include "grid.hpp"
 #include "sparse.hpp"
 
