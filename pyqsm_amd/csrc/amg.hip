@@ -54,7 +54,12 @@ struct AmgLevel {
   int32_t* agg = nullptr;     // fine dof -> coarse dof, -1 = not represented below (absent on the last level)
   int32_t* mptr = nullptr;    // coarse dof -> its fine members (CSR over `members`, ascending)
   int32_t* members = nullptr;
-  double *r = nullptr, *xa = nullptr, *xb = nullptr, *b = nullptr;  // [n,3]; b, xb unused on level 0
+  // the cycle runs in fp32 (it is a preconditioner: 1e-7 of rounding noise is nothing next to
+  // the 1e-2 its CG is asked for, and its sparse passes are gather-bound: 20 bytes per entry
+  // instead of 36); the hierarchy itself is built in fp64
+  float* valsf = nullptr;     // A.vals as float
+  float* dinvf = nullptr;
+  float *r = nullptr, *xa = nullptr, *xb = nullptr, *b = nullptr;  // [n,3]; xb unused on level 0
 };
 
 struct AmgHierarchy {
@@ -306,28 +311,46 @@ __global__ __launch_bounds__(256) void k_rows_to_csr(int nc, const int32_t* __re
   }
 }
 
-// ---- cycle kernels ----------------------------------------------------------------
+// ---- cycle kernels (fp32) ----------------------------------------------------------
+
+__global__ __launch_bounds__(256) void k_to_float(int64_t n, const double* __restrict__ a,
+                                                  float* __restrict__ out) {
+  int64_t i = blockIdx.x * int64_t(256) + threadIdx.x;
+  if (i < n) out[i] = float(a[i]);
+}
+
+// vals, 1/l1 as float
+__global__ __launch_bounds__(256) void k_level_floats(int n, const int32_t* __restrict__ indptr,
+                                                      const double* __restrict__ vals,
+                                                      const double* __restrict__ dinv,
+                                                      float* __restrict__ valsf,
+                                                      float* __restrict__ dinvf) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  for (int j = indptr[i]; j < indptr[i + 1]; ++j) valsf[j] = float(vals[j]);
+  dinvf[i] = float(dinv[i]);
+}
 
 // pre-smoothing from a zero start fused with the residual:
 //   x = Dinv b ;  r = b - A x
 __global__ __launch_bounds__(256) void k_down(int n, const int32_t* __restrict__ indptr,
                                               const int32_t* __restrict__ indices,
-                                              const double* __restrict__ vals,
-                                              const double* __restrict__ dinv,
-                                              const double* __restrict__ b, double* __restrict__ x,
-                                              double* __restrict__ r) {
+                                              const float* __restrict__ vals,
+                                              const float* __restrict__ dinv,
+                                              const float* __restrict__ b, float* __restrict__ x,
+                                              float* __restrict__ r) {
   int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f;
   for (int j = indptr[i]; j < indptr[i + 1]; ++j) {
     const int col = indices[j];
-    const double v = vals[j] * dinv[col];
+    const float v = vals[j] * dinv[col];
     a0 += v * b[3 * col];
     a1 += v * b[3 * col + 1];
     a2 += v * b[3 * col + 2];
   }
-  const double d = dinv[i];
-  const double b0 = b[3 * i], b1 = b[3 * i + 1], b2 = b[3 * i + 2];
+  const float d = dinv[i];
+  const float b0 = b[3 * i], b1 = b[3 * i + 1], b2 = b[3 * i + 2];
   x[3 * i] = d * b0;
   x[3 * i + 1] = d * b1;
   x[3 * i + 2] = d * b2;
@@ -339,11 +362,11 @@ __global__ __launch_bounds__(256) void k_down(int n, const int32_t* __restrict__
 // rc[a] = sum of r over the members of aggregate a
 __global__ __launch_bounds__(256) void k_restrict(int nc, const int32_t* __restrict__ mptr,
                                                   const int32_t* __restrict__ members,
-                                                  const double* __restrict__ r,
-                                                  double* __restrict__ rc) {
+                                                  const float* __restrict__ r,
+                                                  float* __restrict__ rc) {
   int a = blockIdx.x * 256 + threadIdx.x;
   if (a >= nc) return;
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
   for (int m = mptr[a]; m < mptr[a + 1]; ++m) {
     const int i = members[m];
     s0 += r[3 * i];
@@ -357,49 +380,55 @@ __global__ __launch_bounds__(256) void k_restrict(int nc, const int32_t* __restr
 
 // coarse correction fused with the post-smoothing sweep:
 //   y = x + P xc ;  out = y + Dinv (b - A y)
+// TO = double on level 0 (the cycle's result), where `bd` is the caller's fp64 right-hand side
+// and dot += bd . out; float below.
+template <typename TO>
 __global__ __launch_bounds__(256) void k_up(int n, const int32_t* __restrict__ indptr,
                                             const int32_t* __restrict__ indices,
-                                            const double* __restrict__ vals,
-                                            const double* __restrict__ dinv,
+                                            const float* __restrict__ vals,
+                                            const float* __restrict__ dinv,
                                             const int32_t* __restrict__ agg,
-                                            const double* __restrict__ xc,
-                                            const double* __restrict__ b,
-                                            const double* __restrict__ x, double* __restrict__ out,
+                                            const float* __restrict__ xc,
+                                            const float* __restrict__ b,
+                                            const float* __restrict__ x, TO* __restrict__ out,
+                                            const double* __restrict__ bd /*may be null*/,
                                             double* __restrict__ dot /*may be null*/) {
   int i = blockIdx.x * 256 + threadIdx.x;
   double d0 = 0.0, d1 = 0.0, d2 = 0.0;
   if (i < n) {
-  double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-  for (int j = indptr[i]; j < indptr[i + 1]; ++j) {
-    const int col = indices[j];
-    const double v = vals[j];
-    const int ac = agg[col];
-    double y0 = x[3 * col], y1 = x[3 * col + 1], y2 = x[3 * col + 2];
-    if (ac >= 0) {
-      y0 += xc[3 * ac];
-      y1 += xc[3 * ac + 1];
-      y2 += xc[3 * ac + 2];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int j = indptr[i]; j < indptr[i + 1]; ++j) {
+      const int col = indices[j];
+      const float v = vals[j];
+      const int ac = agg[col];
+      float y0 = x[3 * col], y1 = x[3 * col + 1], y2 = x[3 * col + 2];
+      if (ac >= 0) {
+        y0 += xc[3 * ac];
+        y1 += xc[3 * ac + 1];
+        y2 += xc[3 * ac + 2];
+      }
+      a0 += v * y0;
+      a1 += v * y1;
+      a2 += v * y2;
     }
-    a0 += v * y0;
-    a1 += v * y1;
-    a2 += v * y2;
-  }
-  const int ai = agg[i];
-  double y0 = x[3 * i], y1 = x[3 * i + 1], y2 = x[3 * i + 2];
-  if (ai >= 0) {
-    y0 += xc[3 * ai];
-    y1 += xc[3 * ai + 1];
-    y2 += xc[3 * ai + 2];
-  }
-  const double d = dinv[i];
-  const double b0 = b[3 * i], b1 = b[3 * i + 1], b2 = b[3 * i + 2];
-  const double o0 = y0 + d * (b0 - a0), o1 = y1 + d * (b1 - a1), o2 = y2 + d * (b2 - a2);
-  out[3 * i] = o0;
-  out[3 * i + 1] = o1;
-  out[3 * i + 2] = o2;
-  d0 = b0 * o0;
-  d1 = b1 * o1;
-  d2 = b2 * o2;
+    const int ai = agg[i];
+    float y0 = x[3 * i], y1 = x[3 * i + 1], y2 = x[3 * i + 2];
+    if (ai >= 0) {
+      y0 += xc[3 * ai];
+      y1 += xc[3 * ai + 1];
+      y2 += xc[3 * ai + 2];
+    }
+    const float d = dinv[i];
+    const float o0 = y0 + d * (b[3 * i] - a0), o1 = y1 + d * (b[3 * i + 1] - a1),
+                o2 = y2 + d * (b[3 * i + 2] - a2);
+    out[3 * i] = TO(o0);
+    out[3 * i + 1] = TO(o1);
+    out[3 * i + 2] = TO(o2);
+    if (bd) {
+      d0 = bd[3 * i] * double(o0);
+      d1 = bd[3 * i + 1] * double(o1);
+      d2 = bd[3 * i + 2] * double(o2);
+    }
   }
   if (dot) reduce3_atomic(d0, d1, d2, dot);
 }
@@ -407,60 +436,63 @@ __global__ __launch_bounds__(256) void k_up(int n, const int32_t* __restrict__ i
 // one l1-Jacobi sweep out = x + Dinv (b - A x)   (coarsest level without a dense inverse)
 __global__ __launch_bounds__(256) void k_sweep(int n, const int32_t* __restrict__ indptr,
                                                const int32_t* __restrict__ indices,
-                                               const double* __restrict__ vals,
-                                               const double* __restrict__ dinv,
-                                               const double* __restrict__ b,
-                                               const double* __restrict__ x, double* __restrict__ out) {
+                                               const float* __restrict__ vals,
+                                               const float* __restrict__ dinv,
+                                               const float* __restrict__ b,
+                                               const float* __restrict__ x, float* __restrict__ out) {
   int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f;
   for (int j = indptr[i]; j < indptr[i + 1]; ++j) {
     const int col = indices[j];
-    const double v = vals[j];
+    const float v = vals[j];
     a0 += v * x[3 * col];
     a1 += v * x[3 * col + 1];
     a2 += v * x[3 * col + 2];
   }
-  const double d = dinv[i];
+  const float d = dinv[i];
   out[3 * i] = x[3 * i] + d * (b[3 * i] - a0);
   out[3 * i + 1] = x[3 * i + 1] + d * (b[3 * i + 1] - a1);
   out[3 * i + 2] = x[3 * i + 2] + d * (b[3 * i + 2] - a2);
 }
 
 // x = dinv .* b
-__global__ __launch_bounds__(256) void k_scale(int n, const double* __restrict__ dinv,
-                                               const double* __restrict__ b, double* __restrict__ x) {
+__global__ __launch_bounds__(256) void k_scale(int n, const float* __restrict__ dinv,
+                                               const float* __restrict__ b, float* __restrict__ x) {
   int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  const double d = dinv[i];
+  const float d = dinv[i];
 #pragma unroll
   for (int k = 0; k < 3; ++k) x[3 * i + k] = d * b[3 * i + k];
 }
 
-// x = Ainv * b on the coarsest level (nc <= kCoarseMax), one block
+// x = Ainv * b on the coarsest level (nc <= kCoarseMax), one block; the inverse stays fp64
 __global__ __launch_bounds__(128) void k_dense_solve(int nc, const double* __restrict__ ainv,
-                                                     const double* __restrict__ b,
-                                                     double* __restrict__ x) {
+                                                     const float* __restrict__ b,
+                                                     float* __restrict__ x) {
   __shared__ double sb[kCoarseMax * 3];
-  for (int t = threadIdx.x; t < nc * 3; t += blockDim.x) sb[t] = b[t];
+  for (int t = threadIdx.x; t < nc * 3; t += blockDim.x) sb[t] = double(b[t]);
   __syncthreads();
   for (int t = threadIdx.x; t < nc * 3; t += blockDim.x) {
     const int i = t / 3, k = t % 3;
     double s = 0.0;
     for (int j = 0; j < nc; ++j) s += ainv[size_t(i) * nc + j] * sb[3 * j + k];
-    x[t] = s;
+    x[t] = float(s);
   }
 }
 
 // ---- host side ------------------------------------------------------------------------
 
-static int alloc_vectors(Ctx* c, AmgLevel& L, bool coarse) {
+static int alloc_vectors(Ctx* c, AmgLevel& L, bool coarse, int nnz) {
   PQ_TRY(c->arena.get(size_t(L.n) * 3, &L.r));
   PQ_TRY(c->arena.get(size_t(L.n) * 3, &L.xa));
-  if (coarse) {
-    PQ_TRY(c->arena.get(size_t(L.n) * 3, &L.xb));
-    PQ_TRY(c->arena.get(size_t(L.n) * 3, &L.b));
-  }
+  PQ_TRY(c->arena.get(size_t(L.n) * 3, &L.b));  // level 0: the fp32 copy of the right-hand side
+  if (coarse) PQ_TRY(c->arena.get(size_t(L.n) * 3, &L.xb));
+  PQ_TRY(c->arena.get(size_t(nnz) + 1, &L.valsf));
+  PQ_TRY(c->arena.get(size_t(L.n), &L.dinvf));
+  hipLaunchKernelGGL(k_level_floats, dim3(ceil_div(L.n, 256)), dim3(256), 0, c->stream, L.n, L.A.indptr,
+                     L.A.vals, L.dinv, L.valsf, L.dinvf);
+  PQ_HIP(hipGetLastError());
   return 0;
 }
 
@@ -601,7 +633,7 @@ int amg_build(Ctx* c, const DevCsr& Lm, int n, double cw, const double* wh, AmgH
                      Lm.indices, Lm.vals, cw, wh, l0.A.vals);
   hipLaunchKernelGGL(k_diag_l1, dim3(ceil_div(n, 256)), dim3(256), 0, c->stream, n, l0.A.indptr,
                      l0.A.indices, l0.A.vals, l0.diag, l0.dinv);
-  AMG_TRY(alloc_vectors(c, l0, false));
+  AMG_TRY(alloc_vectors(c, l0, false, nnz0));
   H->lv.push_back(l0);
   // ---- coarsen -------------------------------------------------------------------------
   int32_t* d_flag = nullptr;
@@ -646,7 +678,7 @@ int amg_build(Ctx* c, const DevCsr& Lm, int n, double cw, const double* wh, AmgH
     hipLaunchKernelGGL(k_diag_l1, gc, blk, 0, c->stream, nc, C.A.indptr, C.A.indices, C.A.vals, C.diag,
                        C.dinv);
     AMG_HIP(hipGetLastError());
-    AMG_TRY(alloc_vectors(c, C, true));
+    AMG_TRY(alloc_vectors(c, C, true, h2[0]));
     H->lv.push_back(C);
   }
   AmgLevel& last = H->lv.back();
@@ -673,30 +705,32 @@ int amg_levels(const AmgHierarchy* h) { return h ? int(h->lv.size()) : 0; }
 int amg_vcycle(Ctx* c, AmgHierarchy* H, const double* b, double* x, double* dot) {
   const int nl = int(H->lv.size());
   const dim3 blk(256);
+  {  // the cycle works on an fp32 copy of the right-hand side
+    AmgLevel& L0 = H->lv[0];
+    hipLaunchKernelGGL(k_to_float, dim3(ceil_div(int64_t(L0.n) * 3, 256)), blk, 0, c->stream,
+                       int64_t(L0.n) * 3, b, L0.b);
+  }
   // downward sweep: pre-smooth, residual, restrict
   for (int l = 0; l < nl; ++l) {
     AmgLevel& L = H->lv[size_t(l)];
-    const double* bl = l == 0 ? b : L.b;
     const dim3 g(ceil_div(L.n, 256));
-    if (l == nl - 1) {
-      double* xl = l == 0 ? x : L.xb;
+    if (l == nl - 1) {  // (never level 0: hierarchies with a single level are not used)
       if (H->dense_inv) {
-        hipLaunchKernelGGL(k_dense_solve, dim3(1), dim3(128), 0, c->stream, L.n, H->dense_inv, bl, xl);
-      } else {  // kTailSweeps (even) l1-Jacobi sweeps, ending in xl
-        double* other = L.xa;
-        hipLaunchKernelGGL(k_scale, g, blk, 0, c->stream, L.n, L.dinv, bl, xl);
+        hipLaunchKernelGGL(k_dense_solve, dim3(1), dim3(128), 0, c->stream, L.n, H->dense_inv, L.b, L.xb);
+      } else {  // kTailSweeps (even) l1-Jacobi sweeps, ending in xb
+        hipLaunchKernelGGL(k_scale, g, blk, 0, c->stream, L.n, L.dinvf, L.b, L.xb);
         for (int s = 0; s < kTailSweeps; s += 2) {
-          hipLaunchKernelGGL(k_sweep, g, blk, 0, c->stream, L.n, L.A.indptr, L.A.indices, L.A.vals,
-                             L.dinv, bl, xl, other);
-          hipLaunchKernelGGL(k_sweep, g, blk, 0, c->stream, L.n, L.A.indptr, L.A.indices, L.A.vals,
-                             L.dinv, bl, other, xl);
+          hipLaunchKernelGGL(k_sweep, g, blk, 0, c->stream, L.n, L.A.indptr, L.A.indices, L.valsf,
+                             L.dinvf, L.b, L.xb, L.xa);
+          hipLaunchKernelGGL(k_sweep, g, blk, 0, c->stream, L.n, L.A.indptr, L.A.indices, L.valsf,
+                             L.dinvf, L.b, L.xa, L.xb);
         }
       }
       break;
     }
     AmgLevel& C = H->lv[size_t(l) + 1];
-    hipLaunchKernelGGL(k_down, g, blk, 0, c->stream, L.n, L.A.indptr, L.A.indices, L.A.vals, L.dinv, bl,
-                       L.xa, L.r);
+    hipLaunchKernelGGL(k_down, g, blk, 0, c->stream, L.n, L.A.indptr, L.A.indices, L.valsf, L.dinvf,
+                       L.b, L.xa, L.r);
     hipLaunchKernelGGL(k_restrict, dim3(ceil_div(C.n, 256)), blk, 0, c->stream, C.n, L.mptr, L.members,
                        L.r, C.b);
   }
@@ -704,11 +738,15 @@ int amg_vcycle(Ctx* c, AmgHierarchy* H, const double* b, double* x, double* dot)
   for (int l = nl - 2; l >= 0; --l) {
     AmgLevel& L = H->lv[size_t(l)];
     AmgLevel& C = H->lv[size_t(l) + 1];
-    const double* bl = l == 0 ? b : L.b;
-    double* xl = l == 0 ? x : L.xb;
-    hipLaunchKernelGGL(k_up, dim3(ceil_div(L.n, 256)), blk, 0, c->stream, L.n, L.A.indptr, L.A.indices,
-                       L.A.vals, L.dinv, L.agg, C.xb, bl, L.xa, xl,
-                       l == 0 ? dot : static_cast<double*>(nullptr));
+    const dim3 g(ceil_div(L.n, 256));
+    if (l == 0)
+      hipLaunchKernelGGL(k_up<double>, g, blk, 0, c->stream, L.n, L.A.indptr, L.A.indices, L.valsf,
+                         L.dinvf, L.agg, C.xb, L.b, L.xa, x, dot ? b : static_cast<const double*>(nullptr),
+                         dot);
+    else
+      hipLaunchKernelGGL(k_up<float>, g, blk, 0, c->stream, L.n, L.A.indptr, L.A.indices, L.valsf,
+                         L.dinvf, L.agg, C.xb, L.b, L.xa, L.xb, static_cast<const double*>(nullptr),
+                         static_cast<double*>(nullptr));
   }
   PQ_HIP(hipGetLastError());
   return 0;
