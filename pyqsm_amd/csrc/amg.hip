@@ -34,6 +34,7 @@
 #include "sparse.hpp"
 
 #include <cmath>
+#include <type_traits>
 
 namespace pyqsm {
 
@@ -380,9 +381,9 @@ __global__ __launch_bounds__(256) void k_restrict(int nc, const int32_t* __restr
 
 // coarse correction fused with the post-smoothing sweep:
 //   y = x + P xc ;  out = y + Dinv (b - A y)
-// TO = double on level 0 (the cycle's result), where `bd` is the caller's fp64 right-hand side
-// and dot += bd . out; float below.
-template <typename TO>
+// TO = type of the result (double / float on level 0, float below); on level 0 `bd` is the
+// caller's right-hand side and dot += bd . out.
+template <typename TO, typename TBD>
 __global__ __launch_bounds__(256) void k_up(int n, const int32_t* __restrict__ indptr,
                                             const int32_t* __restrict__ indices,
                                             const float* __restrict__ vals,
@@ -391,7 +392,7 @@ __global__ __launch_bounds__(256) void k_up(int n, const int32_t* __restrict__ i
                                             const float* __restrict__ xc,
                                             const float* __restrict__ b,
                                             const float* __restrict__ x, TO* __restrict__ out,
-                                            const double* __restrict__ bd /*may be null*/,
+                                            const TBD* __restrict__ bd /*may be null*/,
                                             double* __restrict__ dot /*may be null*/) {
   int i = blockIdx.x * 256 + threadIdx.x;
   double d0 = 0.0, d1 = 0.0, d2 = 0.0;
@@ -425,9 +426,9 @@ __global__ __launch_bounds__(256) void k_up(int n, const int32_t* __restrict__ i
     out[3 * i + 1] = TO(o1);
     out[3 * i + 2] = TO(o2);
     if (bd) {
-      d0 = bd[3 * i] * double(o0);
-      d1 = bd[3 * i + 1] * double(o1);
-      d2 = bd[3 * i + 2] * double(o2);
+      d0 = double(bd[3 * i]) * double(o0);
+      d1 = double(bd[3 * i + 1]) * double(o1);
+      d2 = double(bd[3 * i + 2]) * double(o2);
     }
   }
   if (dot) reduce3_atomic(d0, d1, d2, dot);
@@ -702,35 +703,43 @@ void amg_destroy(AmgHierarchy* h) { delete h; }
 
 int amg_levels(const AmgHierarchy* h) { return h ? int(h->lv.size()) : 0; }
 
-int amg_vcycle(Ctx* c, AmgHierarchy* H, const double* b, double* x, double* dot) {
+// TV = double: fp64 right-hand side and result (the cycle converts the former);
+// TV = float: both fp32 (the fp32 CG of lbc.hip), no conversion pass.
+template <typename TV>
+static int vcycle_impl(Ctx* c, AmgHierarchy* H, const TV* b, TV* x, double* dot) {
   const int nl = int(H->lv.size());
   const dim3 blk(256);
-  {  // the cycle works on an fp32 copy of the right-hand side
-    AmgLevel& L0 = H->lv[0];
+  AmgLevel& L0 = H->lv[0];
+  const float* b0 = nullptr;
+  if constexpr (std::is_same<TV, double>::value) {  // the cycle works on an fp32 copy
     hipLaunchKernelGGL(k_to_float, dim3(ceil_div(int64_t(L0.n) * 3, 256)), blk, 0, c->stream,
                        int64_t(L0.n) * 3, b, L0.b);
+    b0 = L0.b;
+  } else {
+    b0 = b;
   }
   // downward sweep: pre-smooth, residual, restrict
   for (int l = 0; l < nl; ++l) {
     AmgLevel& L = H->lv[size_t(l)];
+    const float* bl = l == 0 ? b0 : L.b;
     const dim3 g(ceil_div(L.n, 256));
     if (l == nl - 1) {  // (never level 0: hierarchies with a single level are not used)
       if (H->dense_inv) {
-        hipLaunchKernelGGL(k_dense_solve, dim3(1), dim3(128), 0, c->stream, L.n, H->dense_inv, L.b, L.xb);
+        hipLaunchKernelGGL(k_dense_solve, dim3(1), dim3(128), 0, c->stream, L.n, H->dense_inv, bl, L.xb);
       } else {  // kTailSweeps (even) l1-Jacobi sweeps, ending in xb
-        hipLaunchKernelGGL(k_scale, g, blk, 0, c->stream, L.n, L.dinvf, L.b, L.xb);
+        hipLaunchKernelGGL(k_scale, g, blk, 0, c->stream, L.n, L.dinvf, bl, L.xb);
         for (int s = 0; s < kTailSweeps; s += 2) {
           hipLaunchKernelGGL(k_sweep, g, blk, 0, c->stream, L.n, L.A.indptr, L.A.indices, L.valsf,
-                             L.dinvf, L.b, L.xb, L.xa);
+                             L.dinvf, bl, L.xb, L.xa);
           hipLaunchKernelGGL(k_sweep, g, blk, 0, c->stream, L.n, L.A.indptr, L.A.indices, L.valsf,
-                             L.dinvf, L.b, L.xa, L.xb);
+                             L.dinvf, bl, L.xa, L.xb);
         }
       }
       break;
     }
     AmgLevel& C = H->lv[size_t(l) + 1];
-    hipLaunchKernelGGL(k_down, g, blk, 0, c->stream, L.n, L.A.indptr, L.A.indices, L.valsf, L.dinvf,
-                       L.b, L.xa, L.r);
+    hipLaunchKernelGGL(k_down, g, blk, 0, c->stream, L.n, L.A.indptr, L.A.indices, L.valsf, L.dinvf, bl,
+                       L.xa, L.r);
     hipLaunchKernelGGL(k_restrict, dim3(ceil_div(C.n, 256)), blk, 0, c->stream, C.n, L.mptr, L.members,
                        L.r, C.b);
   }
@@ -740,16 +749,30 @@ int amg_vcycle(Ctx* c, AmgHierarchy* H, const double* b, double* x, double* dot)
     AmgLevel& C = H->lv[size_t(l) + 1];
     const dim3 g(ceil_div(L.n, 256));
     if (l == 0)
-      hipLaunchKernelGGL(k_up<double>, g, blk, 0, c->stream, L.n, L.A.indptr, L.A.indices, L.valsf,
-                         L.dinvf, L.agg, C.xb, L.b, L.xa, x, dot ? b : static_cast<const double*>(nullptr),
-                         dot);
+      hipLaunchKernelGGL((k_up<TV, TV>), g, blk, 0, c->stream, L.n, L.A.indptr, L.A.indices, L.valsf,
+                         L.dinvf, L.agg, C.xb, b0, L.xa, x, dot ? b : static_cast<const TV*>(nullptr), dot);
     else
-      hipLaunchKernelGGL(k_up<float>, g, blk, 0, c->stream, L.n, L.A.indptr, L.A.indices, L.valsf,
-                         L.dinvf, L.agg, C.xb, L.b, L.xa, L.xb, static_cast<const double*>(nullptr),
+      hipLaunchKernelGGL((k_up<float, float>), g, blk, 0, c->stream, L.n, L.A.indptr, L.A.indices,
+                         L.valsf, L.dinvf, L.agg, C.xb, L.b, L.xa, L.xb, static_cast<const float*>(nullptr),
                          static_cast<double*>(nullptr));
   }
   PQ_HIP(hipGetLastError());
   return 0;
+}
+
+int amg_vcycle(Ctx* c, AmgHierarchy* H, const double* b, double* x, double* dot) {
+  return vcycle_impl<double>(c, H, b, x, dot);
+}
+
+int amg_vcycle_f32(Ctx* c, AmgHierarchy* H, const float* b, float* x, double* dot) {
+  return vcycle_impl<float>(c, H, b, x, dot);
+}
+
+void amg_fine_matrix(const AmgHierarchy* H, const int32_t** indptr, const int32_t** indices,
+                     const float** vals) {
+  *indptr = H->lv[0].A.indptr;
+  *indices = H->lv[0].A.indices;
+  *vals = H->lv[0].valsf;
 }
 
 }  // namespace pyqsm

@@ -594,6 +594,186 @@ static int amg_pcg(Ctx* c, const System& S, const Work& w, AmgHierarchy* H, cons
                          std::max(resid[0], std::max(resid[1], resid[2])));
 }
 
+// ---- the same CG in fp32 ------------------------------------------------------------------
+// The B-solves are asked for two digits and sit inside a flexible outer CG, so they run in
+// fp32 altogether: B as the multigrid's fp32 level-0 matrix, float vectors, the cycle without
+// its conversion pass; dot products are still accumulated in fp64. Half the bytes per sparse
+// pass and vector update.
+struct WorkF {
+  float *r, *z, *dir, *q;
+  Scal* sc;
+};
+
+__global__ __launch_bounds__(256) void k_bspmv_f(int n, const int32_t* __restrict__ indptr,
+                                                 const int32_t* __restrict__ indices,
+                                                 const float* __restrict__ vals,
+                                                 const float* __restrict__ p, float* __restrict__ q,
+                                                 Scal* __restrict__ sc, int par) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  double pq[3] = {0, 0, 0};
+  if (i < 3) sc->rz[par ^ 1][i] = 0.0;  // the cycle of this iteration accumulates there
+  if (i < n) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int j = indptr[i]; j < indptr[i + 1]; ++j) {
+      const int col = indices[j];
+      const float v = vals[j];
+      a0 += v * p[3 * col];
+      a1 += v * p[3 * col + 1];
+      a2 += v * p[3 * col + 2];
+    }
+    q[3 * i] = a0;
+    q[3 * i + 1] = a1;
+    q[3 * i + 2] = a2;
+    pq[0] = double(p[3 * i]) * a0;
+    pq[1] = double(p[3 * i + 1]) * a1;
+    pq[2] = double(p[3 * i + 2]) * a2;
+  }
+  reduce3_atomic(pq[0], pq[1], pq[2], sc->pq[par]);
+}
+
+__global__ __launch_bounds__(256) void k_update_r_f(int n, const float* __restrict__ dir,
+                                                    const float* __restrict__ q,
+                                                    float* __restrict__ x, float* __restrict__ r,
+                                                    Scal* __restrict__ sc, int par) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  double rr[3] = {0, 0, 0};
+  if (i < n) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const double pqk = sc->pq[par][k];
+      const float alpha = float(pqk != 0.0 ? sc->rz[par][k] / pqk : 0.0);
+      x[3 * i + k] += alpha * dir[3 * i + k];
+      const float ri = r[3 * i + k] - alpha * q[3 * i + k];
+      r[3 * i + k] = ri;
+      rr[k] = double(ri) * ri;
+    }
+  }
+  reduce3_atomic(rr[0], rr[1], rr[2], sc->rr[par]);
+}
+
+__global__ __launch_bounds__(256) void k_direction_f(int n, const float* __restrict__ z,
+                                                     float* __restrict__ dir, Scal* __restrict__ sc,
+                                                     int par) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < 3) {  // slots the next iteration accumulates into
+    sc->pq[par ^ 1][i] = 0.0;
+    sc->rr[par ^ 1][i] = 0.0;
+  }
+  if (i >= n) return;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double rzk = sc->rz[par][k];
+    const float beta = float(rzk != 0.0 ? sc->rz[par ^ 1][k] / rzk : 0.0);
+    dir[3 * i + k] = z[3 * i + k] + beta * dir[3 * i + k];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_dot3_f(int n, const float* __restrict__ a,
+                                                double* __restrict__ out) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  double d[3] = {0, 0, 0};
+  if (i < n) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) d[k] = double(a[3 * i + k]) * a[3 * i + k];
+  }
+  reduce3_atomic(d[0], d[1], d[2], out);
+}
+
+__global__ __launch_bounds__(256) void k_cvt_d2f(int64_t n, const double* __restrict__ a,
+                                                 float* __restrict__ out) {
+  int64_t i = blockIdx.x * int64_t(256) + threadIdx.x;
+  if (i < n) out[i] = float(a[i]);
+}
+
+__global__ __launch_bounds__(256) void k_cvt_f2d(int64_t n, const float* __restrict__ a,
+                                                 double* __restrict__ out) {
+  int64_t i = blockIdx.x * int64_t(256) + threadIdx.x;
+  if (i < n) out[i] = double(a[i]);
+}
+
+// y = B^-1 rhs to rtol, everything fp32 (rhs and y are float [n,3]); y starts at 0.
+static int amg_pcg_f32(Ctx* c, int N, const WorkF& w, AmgHierarchy* H, const float* rhs, float* y,
+                       double rtol, int32_t max_it, GraphCache* cache, int32_t* iters,
+                       double resid[3]) {
+  const dim3 grid(ceil_div(N, 256)), block(256);
+  const int32_t *ip, *ix;
+  const float* bv;
+  amg_fine_matrix(H, &ip, &ix, &bv);
+  PQ_HIP(hipMemsetAsync(w.sc, 0, sizeof(Scal), c->stream));
+  PQ_HIP(hipMemsetAsync(y, 0, size_t(N) * 12, c->stream));
+  PQ_HIP(hipMemcpyAsync(w.r, rhs, size_t(N) * 12, hipMemcpyDeviceToDevice, c->stream));
+  hipLaunchKernelGGL(k_dot3_f, grid, block, 0, c->stream, N, rhs, w.sc->bb);
+  PQ_TRY(amg_vcycle_f32(c, H, w.r, w.z, w.sc->rz[0]));
+  PQ_HIP(hipMemcpyAsync(w.dir, w.z, size_t(N) * 12, hipMemcpyDeviceToDevice, c->stream));
+  for (int k = 0; k < 3; ++k) resid[k] = 1.0;
+  *iters = 0;
+  auto iteration = [&](int par) -> int {
+    hipLaunchKernelGGL(k_bspmv_f, grid, block, 0, c->stream, N, ip, ix, bv, w.dir, w.q, w.sc, par);
+    hipLaunchKernelGGL(k_update_r_f, grid, block, 0, c->stream, N, w.dir, w.q, y, w.r, w.sc, par);
+    PQ_TRY(amg_vcycle_f32(c, H, w.r, w.z, w.sc->rz[par ^ 1]));
+    hipLaunchKernelGGL(k_direction_f, grid, block, 0, c->stream, N, w.z, w.dir, w.sc, par);
+    return 0;
+  };
+  if (!graphs_enabled()) cache = nullptr;
+  auto run_burst = [&](int len) -> int {
+    hipGraphExec_t exec = nullptr;
+    if (cache)
+      for (auto& g : cache->items)
+        if (g.b == static_cast<const void*>(H) && g.x == y && g.op == 200 + len) exec = g.exec;
+    if (cache && !exec) {
+      hipGraph_t graph = nullptr;
+      PQ_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
+      int rc = 0;
+      for (int bi = 0; bi < len && rc == 0; ++bi) rc = iteration(bi & 1);
+      PQ_HIP(hipStreamEndCapture(c->stream, &graph));
+      if (rc != 0) return rc;
+      PQ_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+      (void)hipGraphDestroy(graph);
+      cache->items.push_back({static_cast<const void*>(H), y, 200 + len, exec});
+    }
+    if (exec) {
+      PQ_HIP(hipGraphLaunch(exec, c->stream));
+    } else {
+      for (int bi = 0; bi < len; ++bi) PQ_TRY(iteration(bi & 1));
+    }
+    return 0;
+  };
+  int it = 0;
+  bool done = false;
+  while (!done && it < max_it) {
+    int len = it == 0 ? kAmgFirstBurst : kAmgBurst;
+    if (len > max_it - it) len = std::max(2, (max_it - it + 1) & ~1);
+    {
+      ProfScope ps(c, "lbc_amg_iter", len);
+      PQ_TRY(run_burst(len));
+    }
+    it += len;
+    double h[6];  // rr[1][0..2], bb[0..2] are adjacent in Scal
+    PQ_HIP(hipMemcpyAsync(h, &w.sc->rr[1][0], 48, hipMemcpyDeviceToHost, c->stream));
+    PQ_HIP(hipStreamSynchronize(c->stream));
+    const double* rr = h;
+    const double* bb = h + 3;
+    if (bb[0] == 0.0 && bb[1] == 0.0 && bb[2] == 0.0) {
+      for (int k = 0; k < 3; ++k) resid[k] = 0.0;
+      *iters = it;
+      return 0;
+    }
+    done = true;
+    for (int k = 0; k < 3; ++k) {
+      resid[k] = bb[k] > 0 ? std::sqrt(rr[k] / bb[k]) : 0.0;
+      if (!(resid[k] <= rtol)) done = false;
+      if (!std::isfinite(resid[k])) {
+        *iters = it;
+        return fail(PYQSM_ENOCONV, "multigrid CG (fp32) broke down after %d iterations", it);
+      }
+    }
+  }
+  PQ_HIP(hipGetLastError());
+  *iters = it;
+  return done ? 0 : fail(PYQSM_ENOCONV, "multigrid CG (fp32) reached %d iterations, residual %.3e", it,
+                         std::max(resid[0], std::max(resid[1], resid[2])));
+}
+
 // Device-resident contraction solve.
 //
 // Uniform Laplacian weight c (what extract_skeleton always passes): the system
@@ -661,11 +841,40 @@ static int lbc_solve_core(Ctx* c, const DevCsr& L, int64_t n, const double* wl, 
     const double v = atof(e);
     if (v > 0.0 && v < 1.0) kInnerRtol = v;
   }
+  // fp32 B-solves when they are asked for no more than four digits (the default asks for two);
+  // PYQSM_LBC_F32=0 keeps them in fp64
+  const char* f32e = getenv("PYQSM_LBC_F32");
+  const bool use_f32 = amg && kInnerRtol >= 1e-4 && !(f32e && f32e[0] == '0');
+  WorkF wf{nullptr, nullptr, nullptr, nullptr, nullptr};
+  float *f_rhs = nullptr, *f_y = nullptr, *f_out = nullptr;
+  if (use_f32) {
+    PQ_TRY(c->arena.get(size_t(n) * 3, &wf.r));
+    PQ_TRY(c->arena.get(size_t(n) * 3, &wf.z));
+    PQ_TRY(c->arena.get(size_t(n) * 3, &wf.dir));
+    PQ_TRY(c->arena.get(size_t(n) * 3, &wf.q));
+    PQ_TRY(c->arena.get(size_t(n) * 3, &f_rhs));
+    PQ_TRY(c->arena.get(size_t(n) * 3, &f_y));
+    PQ_TRY(c->arena.get(size_t(n) * 3, &f_out));
+    wf.sc = wb.sc;
+  }
   // max_it caps the total number of inner (sparse-pass) iterations
   auto budget = [&]() { return std::max<int32_t>(1, std::min<int32_t>(kInnerMaxIt, max_it - total_inner)); };
   auto precond = [&](const double* rhs, double* out) -> int {  // out = B^-1 B^-1 rhs
     int32_t it1 = 0, it2 = 0;
     double rs[3];
+    if (amg && use_f32) {
+      const dim3 g3(ceil_div(n * 3, 256));
+      hipLaunchKernelGGL(k_cvt_d2f, g3, block, 0, c->stream, n * 3, rhs, f_rhs);
+      int rc = amg_pcg_f32(c, N, wf, amg, f_rhs, f_y, kInnerRtol, std::min(budget(), kAmgMaxIt), &cache, &it1,
+                           rs);
+      if (rc != 0 && rc != PYQSM_ENOCONV) return rc;
+      total_inner += it1;
+      rc = amg_pcg_f32(c, N, wf, amg, f_y, f_out, kInnerRtol, std::min(budget(), kAmgMaxIt), &cache, &it2, rs);
+      if (rc != 0 && rc != PYQSM_ENOCONV) return rc;
+      total_inner += it2;
+      hipLaunchKernelGGL(k_cvt_f2d, g3, block, 0, c->stream, n * 3, f_out, out);
+      return 0;
+    }
     if (amg) {
       int rc = amg_pcg(c, SB, wb, amg, rhs, y, kInnerRtol, std::min(budget(), kAmgMaxIt), &cache, &it1, rs);
       if (rc != 0 && rc != PYQSM_ENOCONV) return rc;
