@@ -44,6 +44,37 @@ def dbscan(points, eps=None, min_pts=None, device: int = 0):
     return hip.dbscan(as_points(points), eps, min_pts, device=device)
 
 
+def _group_labels(labels, core, pts_idxs):
+    """What fit.py:224-246 computes with ``set(labels)`` and one ``labels == k`` scan per
+    cluster, in O(n): the label set (same elements, same iteration order: labels are inserted in
+    order of first appearance, which is all that a set built from the whole array depends on),
+    the core members of every cluster in that order, and the non-core points labelled -1."""
+    n = len(labels)
+    if n == 0:
+        return set(), [], []
+    k = int(labels.max()) + 2                     # labels are -1 .. k-2
+    shifted = (labels + 1).astype(np.int64)
+    counts = np.bincount(shifted, minlength=k)
+    first = np.zeros(k, dtype=np.int64)
+    first[shifted[::-1]] = np.arange(n - 1, -1, -1)   # last write wins: the smallest position
+    present = np.flatnonzero(counts)
+    unique_labels = set()
+    for v in present[np.argsort(first[present], kind="stable")]:
+        unique_labels.add(np.int64(v - 1))
+    # members of every label in ascending position (what np.where yields), via one stable sort
+    key = shifted.astype(np.int16) if k < 32000 else shifted
+    order = np.argsort(key, kind="stable")
+    bounds = np.concatenate([[0], np.cumsum(counts)])
+    idxs, noise = [], []
+    for lab in unique_labels:
+        members = order[bounds[lab + 1]:bounds[lab + 2]]
+        if lab == -1:
+            noise = pts_idxs[members[~core[members]]]
+        else:
+            idxs.append(pts_idxs[members[core[members]]])
+    return unique_labels, idxs, noise
+
+
 def cluster_DBSCAN(pts_idxs, points, eps, min_pts):
     """fit.py:217-250. Returns ``(unique_labels, idxs, noise)``:
     ``unique_labels`` the set of labels (including -1 when present); ``idxs`` one
@@ -51,17 +82,9 @@ def cluster_DBSCAN(pts_idxs, points, eps, min_pts):
     that cluster's CORE samples only; ``noise`` the caller indices with label -1."""
     labels, core = hip.dbscan(as_points(points), eps, min_pts)
     pts_idxs = np.asarray(pts_idxs)
-    num_clusters = len(set(labels)) - (1 if -1 in labels else 0)
-    num_noise = int((labels == -1).sum())
-    unique_labels = set(labels)
-    idxs = []
-    noise = []
-    for k in unique_labels:
-        member = labels == k
-        if k == -1:
-            noise = pts_idxs[np.where(member & ~core)]
-        else:
-            idxs.append(pts_idxs[np.where(member & core)])
+    unique_labels, idxs, noise = _group_labels(labels, core.astype(bool), pts_idxs)
+    num_clusters = len(unique_labels) - (1 if -1 in unique_labels else 0)
+    num_noise = int(len(labels) - np.count_nonzero(labels + 1))
     log.info(f"Estimated number of clusters: {num_clusters}")
     log.info("Estimated number of noise points: %d" % num_noise)
     return unique_labels, idxs, noise
