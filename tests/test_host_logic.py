@@ -145,3 +145,29 @@ def test_skeleton_loop_bookkeeping_against_oracle():
     assert len(steps) == len(want_steps) >= 2
     assert np.allclose(got.points, want, rtol=0, atol=1e-12)
     assert np.allclose(total, want_total, rtol=0, atol=1e-12)
+
+
+def test_label_grouping_equals_the_reference_loop():
+    """fit.py:224-246 (`set(labels)` + one `labels == k` scan per cluster) against the O(n)
+    grouping of cluster_DBSCAN: same set iteration order, same core members, same noise."""
+    from pyqsm_amd.math_utils.fit import _group_labels
+    rng = np.random.default_rng(0)
+    for trial in range(150):
+        n = int(rng.integers(1, 500))
+        labels = rng.integers(-1, int(rng.integers(1, 60)), n).astype(np.int64)
+        if trial % 3 == 0:
+            labels[labels == -1] = 0
+        core = rng.random(n) < 0.7
+        pts = rng.permutation(n) + 100
+        ul = set(labels)
+        idxs, noise = [], []
+        for k in ul:
+            member = labels == k
+            if k == -1:
+                noise = pts[np.where(member & ~core)]
+            else:
+                idxs.append(pts[np.where(member & core)])
+        ul2, idxs2, noise2 = _group_labels(labels, core, pts)
+        assert list(ul) == list(ul2)
+        assert len(idxs) == len(idxs2) and all(np.array_equal(a, b) for a, b in zip(idxs, idxs2))
+        assert np.array_equal(np.asarray(noise), np.asarray(noise2))
