@@ -394,9 +394,9 @@ __global__ __launch_bounds__(256) void k_up(int n, const int32_t* __restrict__ i
                                             const float* __restrict__ x, TO* __restrict__ out,
                                             const TBD* __restrict__ bd /*may be null*/,
                                             double* __restrict__ dot /*may be null*/) {
-  int i = blockIdx.x * 256 + threadIdx.x;
   double d0 = 0.0, d1 = 0.0, d2 = 0.0;
-  if (i < n) {
+  // grid-stride: with a dot product the launch is capped (the atomics that end it are per block)
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
     for (int j = indptr[i]; j < indptr[i + 1]; ++j) {
       const int col = indices[j];
@@ -426,9 +426,9 @@ __global__ __launch_bounds__(256) void k_up(int n, const int32_t* __restrict__ i
     out[3 * i + 1] = TO(o1);
     out[3 * i + 2] = TO(o2);
     if (bd) {
-      d0 = double(bd[3 * i]) * double(o0);
-      d1 = double(bd[3 * i + 1]) * double(o1);
-      d2 = double(bd[3 * i + 2]) * double(o2);
+      d0 += double(bd[3 * i]) * double(o0);
+      d1 += double(bd[3 * i + 1]) * double(o1);
+      d2 += double(bd[3 * i + 2]) * double(o2);
     }
   }
   if (dot) reduce3_atomic(d0, d1, d2, dot);
@@ -749,7 +749,8 @@ static int vcycle_impl(Ctx* c, AmgHierarchy* H, const TV* b, TV* x, double* dot)
     AmgLevel& C = H->lv[size_t(l) + 1];
     const dim3 g(ceil_div(L.n, 256));
     if (l == 0)
-      hipLaunchKernelGGL((k_up<TV, TV>), g, blk, 0, c->stream, L.n, L.A.indptr, L.A.indices, L.valsf,
+      hipLaunchKernelGGL((k_up<TV, TV>), dot ? dim3(std::min<int64_t>(ceil_div(L.n, 256), 1024)) : g, blk, 0,
+                         c->stream, L.n, L.A.indptr, L.A.indices, L.valsf,
                          L.dinvf, L.agg, C.xb, b0, L.xa, x, dot ? b : static_cast<const TV*>(nullptr), dot);
     else
       hipLaunchKernelGGL((k_up<float, float>), g, blk, 0, c->stream, L.n, L.A.indptr, L.A.indices,

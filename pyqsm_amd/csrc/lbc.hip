@@ -222,11 +222,10 @@ struct S3 {
 __global__ __launch_bounds__(256) void k_dot3(int n, const double* __restrict__ a,
                                               const double* __restrict__ b,
                                               double* __restrict__ out) {
-  int i = blockIdx.x * 256 + threadIdx.x;
   double d[3] = {0, 0, 0};
-  if (i < n) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {  // capped grid
 #pragma unroll
-    for (int k = 0; k < 3; ++k) d[k] = a[3 * i + k] * b[3 * i + k];
+    for (int k = 0; k < 3; ++k) d[k] += a[3 * i + k] * b[3 * i + k];
   }
   reduce3_atomic(d[0], d[1], d[2], out);
 }
@@ -474,7 +473,8 @@ static int jacobi_pcg(Ctx* c, const System& S, const Work& w, const double* b, d
 static int dot3_host(Ctx* c, int n, const double* a, const double* b, double* d_tmp,
                      double out[3]) {
   PQ_HIP(hipMemsetAsync(d_tmp, 0, 24, c->stream));
-  hipLaunchKernelGGL(k_dot3, dim3(ceil_div(n, 256)), dim3(256), 0, c->stream, n, a, b, d_tmp);
+  hipLaunchKernelGGL(k_dot3, dim3(unsigned(std::min<int64_t>(ceil_div(n, 256), 1024))), dim3(256), 0, c->stream,
+                     n, a, b, d_tmp);
   PQ_HIP(hipGetLastError());
   PQ_HIP(hipMemcpyAsync(out, d_tmp, 24, hipMemcpyDeviceToHost, c->stream));
   PQ_HIP(hipStreamSynchronize(c->stream));
@@ -519,7 +519,8 @@ static int amg_pcg(Ctx* c, const System& S, const Work& w, AmgHierarchy* H, cons
   PQ_HIP(hipMemsetAsync(w.sc, 0, sizeof(Scal), c->stream));
   PQ_HIP(hipMemsetAsync(y, 0, size_t(N) * 24, c->stream));
   PQ_HIP(hipMemcpyAsync(w.r, rhs, size_t(N) * 24, hipMemcpyDeviceToDevice, c->stream));
-  hipLaunchKernelGGL(k_dot3, grid, block, 0, c->stream, N, rhs, rhs, w.sc->bb);
+  hipLaunchKernelGGL(k_dot3, dim3(unsigned(std::min<int64_t>(ceil_div(N, 256), 1024))), block, 0, c->stream, N,
+                     rhs, rhs, w.sc->bb);
   PQ_TRY(amg_vcycle(c, H, w.r, w.z, w.sc->rz[0]));
   PQ_HIP(hipMemcpyAsync(w.dir, w.z, size_t(N) * 24, hipMemcpyDeviceToDevice, c->stream));
   for (int k = 0; k < 3; ++k) resid[k] = 1.0;
@@ -599,6 +600,8 @@ static int amg_pcg(Ctx* c, const System& S, const Work& w, AmgHierarchy* H, cons
 // fp32 altogether: B as the multigrid's fp32 level-0 matrix, float vectors, the cycle without
 // its conversion pass; dot products are still accumulated in fp64. Half the bytes per sparse
 // pass and vector update.
+static constexpr int kReduceBlocks = 1024;  // grid cap of kernels whose blocks end in same-address atomics
+
 struct WorkF {
   float *r, *z, *dir, *q;
   Scal* sc;
@@ -609,10 +612,12 @@ __global__ __launch_bounds__(256) void k_bspmv_f(int n, const int32_t* __restric
                                                  const float* __restrict__ vals,
                                                  const float* __restrict__ p, float* __restrict__ q,
                                                  Scal* __restrict__ sc, int par) {
-  int i = blockIdx.x * 256 + threadIdx.x;
+  const int gid = blockIdx.x * 256 + threadIdx.x;
   double pq[3] = {0, 0, 0};
-  if (i < 3) sc->rz[par ^ 1][i] = 0.0;  // the cycle of this iteration accumulates there
-  if (i < n) {
+  if (gid < 3) sc->rz[par ^ 1][gid] = 0.0;  // the cycle of this iteration accumulates there
+  // grid-stride over the rows: the three atomics at the end are per BLOCK, and atomics on one
+  // address are served one at a time (4000 blocks cost ~40 us of a 70 us kernel)
+  for (int i = gid; i < n; i += gridDim.x * 256) {
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
     for (int j = indptr[i]; j < indptr[i + 1]; ++j) {
       const int col = indices[j];
@@ -624,9 +629,9 @@ __global__ __launch_bounds__(256) void k_bspmv_f(int n, const int32_t* __restric
     q[3 * i] = a0;
     q[3 * i + 1] = a1;
     q[3 * i + 2] = a2;
-    pq[0] = double(p[3 * i]) * a0;
-    pq[1] = double(p[3 * i + 1]) * a1;
-    pq[2] = double(p[3 * i + 2]) * a2;
+    pq[0] += double(p[3 * i]) * a0;
+    pq[1] += double(p[3 * i + 1]) * a1;
+    pq[2] += double(p[3 * i + 2]) * a2;
   }
   reduce3_atomic(pq[0], pq[1], pq[2], sc->pq[par]);
 }
@@ -635,17 +640,20 @@ __global__ __launch_bounds__(256) void k_update_r_f(int n, const float* __restri
                                                     const float* __restrict__ q,
                                                     float* __restrict__ x, float* __restrict__ r,
                                                     Scal* __restrict__ sc, int par) {
-  int i = blockIdx.x * 256 + threadIdx.x;
   double rr[3] = {0, 0, 0};
-  if (i < n) {
+  float alpha[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double pqk = sc->pq[par][k];
+    alpha[k] = float(pqk != 0.0 ? sc->rz[par][k] / pqk : 0.0);
+  }
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      const double pqk = sc->pq[par][k];
-      const float alpha = float(pqk != 0.0 ? sc->rz[par][k] / pqk : 0.0);
-      x[3 * i + k] += alpha * dir[3 * i + k];
-      const float ri = r[3 * i + k] - alpha * q[3 * i + k];
+      x[3 * i + k] += alpha[k] * dir[3 * i + k];
+      const float ri = r[3 * i + k] - alpha[k] * q[3 * i + k];
       r[3 * i + k] = ri;
-      rr[k] = double(ri) * ri;
+      rr[k] += double(ri) * ri;
     }
   }
   reduce3_atomic(rr[0], rr[1], rr[2], sc->rr[par]);
@@ -670,11 +678,10 @@ __global__ __launch_bounds__(256) void k_direction_f(int n, const float* __restr
 
 __global__ __launch_bounds__(256) void k_dot3_f(int n, const float* __restrict__ a,
                                                 double* __restrict__ out) {
-  int i = blockIdx.x * 256 + threadIdx.x;
   double d[3] = {0, 0, 0};
-  if (i < n) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) d[k] = double(a[3 * i + k]) * a[3 * i + k];
+    for (int k = 0; k < 3; ++k) d[k] += double(a[3 * i + k]) * a[3 * i + k];
   }
   reduce3_atomic(d[0], d[1], d[2], out);
 }
@@ -702,14 +709,15 @@ static int amg_pcg_f32(Ctx* c, int N, const WorkF& w, AmgHierarchy* H, const flo
   PQ_HIP(hipMemsetAsync(w.sc, 0, sizeof(Scal), c->stream));
   PQ_HIP(hipMemsetAsync(y, 0, size_t(N) * 12, c->stream));
   PQ_HIP(hipMemcpyAsync(w.r, rhs, size_t(N) * 12, hipMemcpyDeviceToDevice, c->stream));
-  hipLaunchKernelGGL(k_dot3_f, grid, block, 0, c->stream, N, rhs, w.sc->bb);
+  const dim3 rgrid(unsigned(std::min<int64_t>(ceil_div(N, 256), kReduceBlocks)));  // kernels that end in atomics
+  hipLaunchKernelGGL(k_dot3_f, rgrid, block, 0, c->stream, N, rhs, w.sc->bb);
   PQ_TRY(amg_vcycle_f32(c, H, w.r, w.z, w.sc->rz[0]));
   PQ_HIP(hipMemcpyAsync(w.dir, w.z, size_t(N) * 12, hipMemcpyDeviceToDevice, c->stream));
   for (int k = 0; k < 3; ++k) resid[k] = 1.0;
   *iters = 0;
   auto iteration = [&](int par) -> int {
-    hipLaunchKernelGGL(k_bspmv_f, grid, block, 0, c->stream, N, ip, ix, bv, w.dir, w.q, w.sc, par);
-    hipLaunchKernelGGL(k_update_r_f, grid, block, 0, c->stream, N, w.dir, w.q, y, w.r, w.sc, par);
+    hipLaunchKernelGGL(k_bspmv_f, rgrid, block, 0, c->stream, N, ip, ix, bv, w.dir, w.q, w.sc, par);
+    hipLaunchKernelGGL(k_update_r_f, rgrid, block, 0, c->stream, N, w.dir, w.q, y, w.r, w.sc, par);
     PQ_TRY(amg_vcycle_f32(c, H, w.r, w.z, w.sc->rz[par ^ 1]));
     hipLaunchKernelGGL(k_direction_f, grid, block, 0, c->stream, N, w.z, w.dir, w.sc, par);
     return 0;
