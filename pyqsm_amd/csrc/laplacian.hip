@@ -453,17 +453,33 @@ __device__ __host__ inline bool flip_candidate(int h, const double* fl, const in
 // half-edge ids), so the sequence of flips — and the result — does not depend on it.
 
 // Every lane contributes `cnt` slots; returns this lane's first slot in the list.
-__device__ __forceinline__ int wave_reserve(int cnt, int32_t* counter) {
-  int incl = cnt;
+// (One atomic per BLOCK of 256: atomics on a single address are served one at a time, and a
+// round over a 2.5 M-entry list would otherwise issue 40 000 of them. Every thread of the block
+// must call this.) `extra` is a second per-thread count folded the same way into counter[1].
+__device__ __forceinline__ int block_reserve(int cnt, int extra, int32_t* counter) {
+  __shared__ int wtot[4], wext[4], bbase;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int incl = cnt, ex = extra;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
     const int v = __shfl_up(incl, off, 64);
-    if ((threadIdx.x & 63) >= off) incl += v;
+    if (lane >= off) incl += v;
   }
-  const int total = __shfl(incl, 63, 64);
-  int base = 0;
-  if ((threadIdx.x & 63) == 0 && total > 0) base = atomicAdd(counter, total);
-  base = __shfl(base, 0, 64);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) ex += __shfl_xor(ex, off, 64);
+  if (lane == 63) wtot[w] = incl;
+  if (lane == 0) wext[w] = ex;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int tot = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    const int et = wext[0] + wext[1] + wext[2] + wext[3];
+    bbase = tot > 0 ? atomicAdd(counter, tot) : 0;
+    if (et > 0) atomicAdd(counter + 1, et);
+  }
+  __syncthreads();
+  int base = bbase;
+  for (int k = 0; k < w; ++k) base += wtot[k];
+  __syncthreads();  // the shared slots are reused by the next call
   return base + incl - cnt;
 }
 
@@ -474,7 +490,7 @@ __global__ __launch_bounds__(256) void k_flip_seed(int H, const double* __restri
   int h = blockIdx.x * 256 + threadIdx.x;
   FlipInfo q;
   const bool cand = h < H && flip_candidate(h, fl, fn, &q);
-  const int slot = wave_reserve(cand ? 1 : 0, count);
+  const int slot = block_reserve(cand ? 1 : 0, 0, count);
   if (cand) list[slot] = h;
 }
 
@@ -604,10 +620,8 @@ __global__ __launch_bounds__(256) void k_flip_apply(const int32_t* __restrict__ 
   int keep = 0;
   for (int p = 0; p < np; ++p)
     if (atomicExch(&mark[push[p]], round_id + 1) != round_id + 1) push[keep++] = push[p];
-  int slot = wave_reserve(keep, counts);
+  int slot = block_reserve(keep, flipped ? 1 : 0, counts);
   for (int p = 0; p < keep; ++p) next[slot++] = push[p];
-  const unsigned long long fb = __ballot(flipped);
-  if (fb != 0 && (threadIdx.x & 63) == 0) atomicAdd(counts + 1, __popcll(fb));
   }
 }
 
