@@ -167,8 +167,15 @@ __global__ __launch_bounds__(256) void k_mis_update(int n, const unsigned long l
       still = true;
     }
   }
+  // one atomic per block (atomics on one address are served one at a time)
+  __shared__ int wleft[4];
   const unsigned long long b = __ballot(still);
-  if (b != 0 && (threadIdx.x & 63) == 0) atomicAdd(left, __popcll(b));
+  if ((threadIdx.x & 63) == 0) wleft[threadIdx.x >> 6] = __popcll(b);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int t = wleft[0] + wleft[1] + wleft[2] + wleft[3];
+    if (t > 0) atomicAdd(left, t);
+  }
 }
 
 __global__ __launch_bounds__(256) void k_root_flags(int n, const int32_t* __restrict__ state,

@@ -229,9 +229,19 @@ __global__ __launch_bounds__(256) void k_knn_reg(int n_query, KnnGrid g,
     if (kth <= safe * safe) done = true;
     if (r >= rmax_grid) done = true;  // the cube already covers the whole grid
   }
-  if (!done && !last_level) {
-    fail_list[atomicAdd(fail_count, 1)] = self;
-    return;
+  // one atomic per wave for the queries that stay open (per lane it was ~10^4 atomics on one
+  // address per million points)
+  const bool open = !done && !last_level;
+  const unsigned long long ob = __ballot(open);
+  if (ob != 0) {
+    const int lane = threadIdx.x & 63, lead = __ffsll(ob) - 1;
+    int base = 0;
+    if (lane == lead) base = atomicAdd(fail_count, __popcll(ob));
+    base = __shfl(base, lead, 64);
+    if (open) {
+      fail_list[base + __popcll(ob & ((1ull << lane) - 1ull))] = self;
+      return;
+    }
   }
 #pragma unroll
   for (int j = 0; j < K; ++j)
