@@ -563,13 +563,22 @@ __global__ __launch_bounds__(256) void k_labels(int n, const uint8_t* __restrict
   const bool is_c = live && core[p];
   if (is_c) labels[order[p]] = int64_t(rank[min_orig[parent[p]]]);
   if (live && is_core) is_core[order[p]] = is_c;
+  // block-aggregated append (one atomic per 256 threads)
+  __shared__ int wcount[4], wbase[4];
   const unsigned long long nb = __ballot(live && !is_c);
-  if (nb == 0) return;
-  const int lane = threadIdx.x & 63, lead = __ffsll(nb) - 1;
-  int slot = 0;
-  if (lane == lead) slot = atomicAdd(rest_cnt, __popcll(nb));
-  slot = __shfl(slot, lead, 64);
-  if (live && !is_c) rest[slot + __popcll(nb & ((1ull << lane) - 1ull))] = p;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) wcount[w] = __popcll(nb);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int tot = wcount[0] + wcount[1] + wcount[2] + wcount[3];
+    const int base = tot ? atomicAdd(rest_cnt, tot) : 0;
+    wbase[0] = base;
+    wbase[1] = base + wcount[0];
+    wbase[2] = base + wcount[0] + wcount[1];
+    wbase[3] = base + wcount[0] + wcount[1] + wcount[2];
+  }
+  __syncthreads();
+  if (live && !is_c) rest[wbase[w] + __popcll(nb & ((1ull << lane) - 1ull))] = p;
 }
 
 // One WAVE per non-core point: smallest cluster number among its core neighbours, or -1.
