@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void k_init_parent(int n, int* __restrict__ pa
 
 // The first point of every sub-cell run finds the run's first core point (the sub-cell's
 // representative), hangs the other core points of the run under it and lists it.
-__global__ __launch_bounds__(256) void k_sub_rep(int n, const int32_t* __restrict__ sub_of,
+__global__ __launch_bounds__(1024) void k_sub_rep(int n, const int32_t* __restrict__ sub_of,
                                                  const int32_t* __restrict__ sub_beg,
                                                  const int32_t* __restrict__ sub_cnt,
                                                  const uint8_t* __restrict__ core,
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void k_sub_rep(int n, const int32_t* __restric
                                                  int* __restrict__ run_min,
                                                  int4* __restrict__ list,
                                                  int32_t* __restrict__ list_cnt) {
-  int p = blockIdx.x * 256 + threadIdx.x;
+  int p = blockIdx.x * 1024 + threadIdx.x;
   int rep = -1, sid = 0, e = 0;
   if (p < n) {
     sid = sub_of[p];
@@ -290,20 +290,22 @@ __global__ __launch_bounds__(256) void k_sub_rep(int n, const int32_t* __restric
       }
     }
   }
-  // block-aggregated append of the representatives: one atomic per block (atomics on a
-  // single address are served one at a time; one per wave cost 0.16 ms per million points)
-  __shared__ int wcount[4], wbase[4];
+  // block-aggregated append of the representatives: one atomic per block of 1024 threads
+  // (atomics on a single address are served one at a time: one per wave cost 0.16 ms per
+  // million points, one per 256 threads still 0.04 ms)
+  __shared__ int wcount[16], wbase[16];
   const unsigned long long b = __ballot(rep >= 0);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (lane == 0) wcount[w] = __popcll(b);
   __syncthreads();
   if (threadIdx.x == 0) {
-    const int tot = wcount[0] + wcount[1] + wcount[2] + wcount[3];
-    const int base = tot ? atomicAdd(list_cnt, tot) : 0;
-    wbase[0] = base;
-    wbase[1] = base + wcount[0];
-    wbase[2] = base + wcount[0] + wcount[1];
-    wbase[3] = base + wcount[0] + wcount[1] + wcount[2];
+    int tot = 0;
+    for (int k = 0; k < 16; ++k) tot += wcount[k];
+    int base = tot ? atomicAdd(list_cnt, tot) : 0;
+    for (int k = 0; k < 16; ++k) {
+      wbase[k] = base;
+      base += wcount[k];
+    }
   }
   __syncthreads();
   // list record: representative, its cell, its sub-cell id, points from it to the run's end
@@ -679,7 +681,7 @@ static int dbscan_device(Ctx* c, const double* xyz, int64_t n, double eps, int32
     PQ_HIP(hipMemsetAsync(flag, 0, (size_t(n) + 1) * 4, c->stream));
     if (fine) {
       PQ_HIP(hipMemsetAsync(list_cnt, 0, 4, c->stream));
-      hipLaunchKernelGGL(k_sub_rep, grid, block, 0, c->stream, N, sub.sub_of, sub.sub_beg, sub.sub_cnt,
+      hipLaunchKernelGGL(k_sub_rep, dim3(ceil_div(n, 1024)), dim3(1024), 0, c->stream, N, sub.sub_of, sub.sub_beg, sub.sub_cnt,
                          core, g.order, parent, g.cell_of, sub.rec, run_min, list, list_cnt);
       int32_t m = 0;
       PQ_HIP(hipMemcpyAsync(&m, list_cnt, 4, hipMemcpyDeviceToHost, c->stream));
