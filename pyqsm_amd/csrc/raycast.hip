@@ -634,11 +634,17 @@ __global__ __launch_bounds__(256) void k_dir_sum(const float* __restrict__ rays,
     sy += __shfl_down(sy, off, 64);
     sz += __shfl_down(sz, off, 64);
   }
+  // one set of atomics per block
+  __shared__ double ws[4][3];
   if ((threadIdx.x & 63) == 0) {
-    atomicAdd(sum, sx);
-    atomicAdd(sum + 1, sy);
-    atomicAdd(sum + 2, sz);
+    ws[threadIdx.x >> 6][0] = sx;
+    ws[threadIdx.x >> 6][1] = sy;
+    ws[threadIdx.x >> 6][2] = sz;
   }
+  __syncthreads();
+  if (threadIdx.x < 3)
+    atomicAdd(sum + threadIdx.x, (ws[0][threadIdx.x] + ws[1][threadIdx.x]) +
+                                     (ws[2][threadIdx.x] + ws[3][threadIdx.x]));
 }
 
 // image coordinates of every ray (as [R][3] points for the bounding-box pass); flags rays
@@ -1044,7 +1050,7 @@ static int launch_cast(Ctx* c, const TriRec* tri, int64_t T, const float* rays, 
     double* d_sum = nullptr;
     PQ_TRY(c->arena.get(3, &d_sum));
     PQ_HIP(hipMemsetAsync(d_sum, 0, 24, c->stream));
-    hipLaunchKernelGGL(k_dir_sum, dim3(std::min<int64_t>(ceil_div(R, 256), 1024)), dim3(256), 0,
+    hipLaunchKernelGGL(k_dir_sum, dim3(std::min<int64_t>(ceil_div(R, 256), 512)), dim3(256), 0,
                        c->stream, rays, R, d_sum);
     double hs[3];
     float ho[12];
