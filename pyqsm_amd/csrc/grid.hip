@@ -146,7 +146,10 @@ __global__ __launch_bounds__(256) void k_probe_count(const double* __restrict__ 
                                                      GridParams g, int32_t* __restrict__ counts) {
   int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
   if (i >= n) return;
-  atomicAdd(&counts[cell_index(g, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2])], 1);
+  // only "occupied or not" is read afterwards: a plain store of 1 (racing stores of the same
+  // value) instead of a counter — hundreds of points share a probe cell, and atomics on one
+  // address are served one at a time
+  counts[cell_index(g, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2])] = 1;
 }
 
 __global__ __launch_bounds__(256) void k_count_nonzero(const int32_t* __restrict__ counts,
