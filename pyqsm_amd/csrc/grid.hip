@@ -131,15 +131,26 @@ __global__ __launch_bounds__(256) void k_cell_scatter(const double* __restrict__
   sz[p] = xyz[3 * i + 2];
 }
 
+// wave sums -> one atomic per block (atomics on one address are served one at a time)
+__device__ __forceinline__ void block_add_i32(int32_t local, int32_t* out) {
+  __shared__ int32_t wsum[4];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = local;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int32_t t = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+    if (t) atomicAdd(out, t);
+  }
+}
+
 __global__ __launch_bounds__(256) void k_count_occupied(const int32_t* __restrict__ start,
                                                         int64_t ncell, int32_t* __restrict__ out) {
   int32_t local = 0;
   for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < ncell;
        i += int64_t(gridDim.x) * blockDim.x)
     local += start[i + 1] > start[i];
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
-  if ((threadIdx.x & 63) == 0 && local) atomicAdd(out, local);
+  block_add_i32(local, out);
 }
 
 __global__ __launch_bounds__(256) void k_probe_count(const double* __restrict__ xyz, int64_t n,
@@ -158,9 +169,7 @@ __global__ __launch_bounds__(256) void k_count_nonzero(const int32_t* __restrict
   for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < ncell;
        i += int64_t(gridDim.x) * blockDim.x)
     local += counts[i] > 0;
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
-  if ((threadIdx.x & 63) == 0 && local) atomicAdd(out, local);
+  block_add_i32(local, out);
 }
 
 int probe_occupancy(Ctx* c, const double* xyz, int64_t n, const double box[6], double cell,
