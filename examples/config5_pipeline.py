@@ -10,6 +10,7 @@ line with the per-stage times is printed. At --scale 1 this is the 5 M-point / 5
 configuration; the ray stage is the only one that shards over several GPUs (bench.py)."""
 import argparse
 import json
+from concurrent.futures import ThreadPoolExecutor
 import os
 import sys
 import time
@@ -29,6 +30,9 @@ def main():
     ap.add_argument("--scale", type=float, default=0.04)
     ap.add_argument("--skeleton-iters", type=int, default=3)
     ap.add_argument("--max-trees", type=int, default=2, help="trees that get skeletonised")
+    ap.add_argument("--workers", type=int, default=8,
+                    help="host threads that contract trees concurrently (the library keeps one "
+                         "stream and arena per thread; a 50 k-point tree alone is latency-bound)")
     args = ap.parse_args()
     _lib.require_gpu(0)
     n_points = max(50_000, int(5_000_000 * args.scale))
@@ -45,14 +49,16 @@ def main():
     idxs = sorted(idxs, key=len, reverse=True)
 
     t0 = time.perf_counter()
-    shifts = []
-    for tree in idxs[: args.max_trees]:
-        cloud = pts[tree]
-        contracted, total_shift, steps = extract_skeleton(cloud, max_iter=args.skeleton_iters,
+    def contract(tree):
+        contracted, total_shift, steps = extract_skeleton(pts[tree], max_iter=args.skeleton_iters,
                                                           termination_ratio=0.0)
-        shifts.append(float(np.linalg.norm(total_shift, axis=1).mean()))
+        return float(np.linalg.norm(total_shift, axis=1).mean())
+
+    with ThreadPoolExecutor(max_workers=max(1, args.workers)) as pool:
+        shifts = list(pool.map(contract, idxs[: args.max_trees]))
     out["skeleton_s"] = time.perf_counter() - t0
     out["skeleton_trees"] = len(shifts)
+    out["skeleton_workers"] = max(1, args.workers)
     out["mean_contraction_m"] = shifts
 
     t0 = time.perf_counter()

@@ -18,7 +18,9 @@
  *     "_dev" entry points take device pointers (HBM-resident input/output,
  *     obtained from pyqsm_dev_malloc or any hipMalloc'd allocation) and are
  *     asynchronous on the library's per-device stream until pyqsm_sync()
- *   - the library owns one HIP stream and one scratch arena per device
+ *   - the library owns one HIP stream and one scratch arena per device and
+ *     calling thread: threads may call concurrently, each is ordered on its own
+ *     stream (pyqsm_stream / pyqsm_sync / pyqsm_prof_* act on the caller's)
  */
 #ifndef PYQSM_HIP_H
 #define PYQSM_HIP_H
@@ -45,7 +47,7 @@ extern "C" {
 
 /* Number of visible GPUs (0 when none); never fails. */
 int pyqsm_device_count(void);
-/* Create the per-device context (stream + arena). Idempotent. */
+/* Create the calling thread's context for `device` (stream + arena). Idempotent. */
 int pyqsm_init(int device);
 /* Destroy every context created by pyqsm_init. */
 int pyqsm_shutdown(void);

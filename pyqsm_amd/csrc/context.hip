@@ -74,13 +74,41 @@ void Arena::destroy() {
 
 // ---- contexts -----------------------------------------------------------
 
+// One context (stream + scratch arena + timers) per device AND calling thread, so that
+// host threads can drive independent work on one GPU concurrently: small clouds are
+// launch- and sync-latency bound (a 50 k-point tree keeps a few CUs busy), and N trees on
+// N threads overlap on the device instead of queueing behind one mutex. A thread keeps its
+// contexts until it exits; they then go back to an idle list and are handed to the next
+// new thread, so a thread pool that comes and goes does not grow the arenas.
 static std::mutex g_mu;
-static std::map<int, Ctx*> g_ctx;
+struct Pool {
+  std::vector<Ctx*> all, idle;
+};
+static std::map<int, Pool>& pools() {
+  static auto* p = new std::map<int, Pool>();  // never destroyed: threads may outlive exit()
+  return *p;
+}
+static unsigned g_generation = 0;  // bumped by pyqsm_shutdown: held pointers are stale after it
+
+struct ThreadHeld {
+  unsigned generation = 0;
+  std::map<int, Ctx*> ctx;
+  ~ThreadHeld() {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (generation != g_generation) return;
+    for (auto& kv : ctx) pools()[kv.first].idle.push_back(kv.second);
+  }
+};
+static thread_local ThreadHeld t_held;
 
 Ctx* ctx_for(int device) {
   std::lock_guard<std::mutex> lk(g_mu);
-  auto it = g_ctx.find(device);
-  if (it != g_ctx.end()) {
+  if (t_held.generation != g_generation) {
+    t_held.ctx.clear();
+    t_held.generation = g_generation;
+  }
+  auto it = t_held.ctx.find(device);
+  if (it != t_held.ctx.end()) {
     (void)hipSetDevice(device);
     return it->second;
   }
@@ -98,6 +126,13 @@ Ctx* ctx_for(int device) {
     set_error("hipSetDevice(%d): %s", device, hipGetErrorString(e));
     return nullptr;
   }
+  Pool& pool = pools()[device];
+  if (!pool.idle.empty()) {
+    Ctx* c = pool.idle.back();
+    pool.idle.pop_back();
+    t_held.ctx[device] = c;
+    return c;
+  }
   Ctx* c = new Ctx();
   c->device = device;
   if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
@@ -107,7 +142,8 @@ Ctx* ctx_for(int device) {
   }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->cu_count = prop.multiProcessorCount;
-  g_ctx[device] = c;
+  pool.all.push_back(c);
+  t_held.ctx[device] = c;
   return c;
 }
 
@@ -167,16 +203,18 @@ int pyqsm_init(int device) { return ctx_for(device) ? 0 : PYQSM_ENODEV; }
 
 int pyqsm_shutdown(void) {
   std::lock_guard<std::mutex> lk(g_mu);
-  for (auto& kv : g_ctx) {
-    Ctx* c = kv.second;
-    (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
-    drain_timers(c);
-    c->arena.destroy();
-    (void)hipStreamDestroy(c->stream);
-    delete c;
+  for (auto& kv : pools()) {
+    for (Ctx* c : kv.second.all) {
+      (void)hipSetDevice(c->device);
+      (void)hipStreamSynchronize(c->stream);
+      drain_timers(c);
+      c->arena.destroy();
+      (void)hipStreamDestroy(c->stream);
+      delete c;
+    }
   }
-  g_ctx.clear();
+  pools().clear();
+  ++g_generation;
   return 0;
 }
 

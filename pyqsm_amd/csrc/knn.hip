@@ -25,6 +25,8 @@
 // Distances are squared, fp64, ((dx*dx)+dy*dy)+dz*dz with separately rounded
 // products — the accumulation order of scipy's cKDTree — and candidates are
 // ordered by (d2, original index).
+#include <atomic>
+
 #include "grid.hpp"
 
 #include <cmath>
@@ -396,11 +398,12 @@ static int launch_knn(Ctx* c, int n_query, const int32_t* list, const int32_t* p
                       const DevGrid& g, int k, int excl, int n_total, int last, int32_t* idx,
                       double* d2, int32_t* fail_list, int32_t* fail_count) {
   const size_t smem = size_t(k) * T * 12;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<uint64_t> attr_set{0};  // one bit per device (the attribute is per device)
+  const uint64_t bit = 1ull << (c->device & 63);
+  if (!(attr_set.load(std::memory_order_acquire) & bit)) {
     PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_knn<T>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
+    attr_set.fetch_or(bit, std::memory_order_release);
   }
   KnnGrid kg{g.nx, g.ny, g.nz, g.cell};
   hipLaunchKernelGGL(k_knn<T>, dim3(ceil_div(n_query, T)), dim3(T), smem, c->stream, n_query, list,
