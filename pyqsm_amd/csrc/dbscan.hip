@@ -317,6 +317,11 @@ __global__ __launch_bounds__(1024) void k_sub_rep(int n, const int32_t* __restri
 // of max-norm 1 first, then the 49 of max-norm 2.
 __constant__ signed char kSubOffsets[62][3] = {{1,0,0}, {-1,1,0}, {0,1,0}, {1,1,0}, {-1,-1,1}, {0,-1,1}, {1,-1,1}, {-1,0,1}, {0,0,1}, {1,0,1}, {-1,1,1}, {0,1,1}, {1,1,1}, {2,0,0}, {-2,1,0}, {2,1,0}, {-2,2,0}, {-1,2,0}, {0,2,0}, {1,2,0}, {2,2,0}, {-2,-2,1}, {-1,-2,1}, {0,-2,1}, {1,-2,1}, {2,-2,1}, {-2,-1,1}, {2,-1,1}, {-2,0,1}, {2,0,1}, {-2,1,1}, {2,1,1}, {-2,2,1}, {-1,2,1}, {0,2,1}, {1,2,1}, {2,2,1}, {-2,-2,2}, {-1,-2,2}, {0,-2,2}, {1,-2,2}, {2,-2,2}, {-2,-1,2}, {-1,-1,2}, {0,-1,2}, {1,-1,2}, {2,-1,2}, {-2,0,2}, {-1,0,2}, {0,0,2}, {1,0,2}, {2,0,2}, {-2,1,2}, {-1,1,2}, {0,1,2}, {1,1,2}, {2,1,2}, {-2,2,2}, {-1,2,2}, {0,2,2}, {1,2,2}, {2,2,2}};
 
+// Sub-cells one wave of the two passes below takes: a wave per sub-cell (200 k waves of a
+// few hundred cycles each per million points) was bound by the rate at which waves START
+// (resident waves: 13-21 % of the slots), not by what they did.
+static constexpr int kSubPerWave = 4;
+
 // Full path compression for the listed representatives (plain accesses: the kernel
 // boundary makes the unions of the previous launch visible, and any value another lane
 // writes meanwhile is an ancestor too).
@@ -343,115 +348,148 @@ __global__ __launch_bounds__(256) void k_hook_sub(const int4* __restrict__ list,
                                                   const double* __restrict__ sy,
                                                   const double* __restrict__ sz, double r2,
                                                   const uint8_t* __restrict__ core,
-                                                  int* __restrict__ parent) {
-  const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (s >= m) return;  // wave-uniform
+                                                  int* __restrict__ parent,
+                                                  int32_t* __restrict__ nbr) {
+  const int s0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * kSubPerWave;
+  if (s0 >= m) return;  // wave-uniform
   const int k = threadIdx.x & 63;
-  const int4 me = list[s];  // one 16-byte load instead of three dependent ones
-  const int p = me.x, c1 = me.y, o1 = me.z & 7, n1 = me.w;
-  const int cx = c1 % nx, cy = (c1 / nx) % ny, cz = c1 / (nx * ny);
-  int q0 = 0, n2 = 0, rep2 = -1;
-  if (k < 62) {
-    const int gx = 2 * (cx - 1) + (o1 & 1) - kSubOffsets[k][0],
-              gy = 2 * (cy - 1) + ((o1 >> 1) & 1) - kSubOffsets[k][1],
-              gz = 2 * (cz - 1) + ((o1 >> 2) & 1) - kSubOffsets[k][2];
+  const int o_dx = k < 62 ? kSubOffsets[k][0] : 0, o_dy = k < 62 ? kSubOffsets[k][1] : 0,
+            o_dz = k < 62 ? kSubOffsets[k][2] : 0;
+  // the dependent loads (list -> start -> rec) of the wave's sub-cells are issued side by side.
+  // (What these kernels cost is the number of cache LINES their gathers touch — one per
+  // neighbouring cell and table, taken by the L1 a line at a time. Dropping the second gather
+  // start[c2 + 1] by tagging the records with their cell cost more than it saved: lanes of
+  // empty cells then fetch the next occupied cell's records.)
+  int4 me[kSubPerWave];
+  int b2[kSubPerWave], e2[kSubPerWave], oct[kSubPerWave];
+#pragma unroll
+  for (int u = 0; u < kSubPerWave; ++u) me[u] = list[min(s0 + u, m - 1)];  // 16 bytes, wave-uniform
+#pragma unroll
+  for (int u = 0; u < kSubPerWave; ++u) {
+    const int c1 = me[u].y, o1 = me[u].z & 7;
+    const int cx = c1 % nx, cy = (c1 / nx) % ny, cz = c1 / (nx * ny);
+    // half-cell coordinates (cell 1 is the first interior cell; borders are empty)
+    const int gx = 2 * (cx - 1) + (o1 & 1) - o_dx, gy = 2 * (cy - 1) + ((o1 >> 1) & 1) - o_dy,
+              gz = 2 * (cz - 1) + ((o1 >> 2) & 1) - o_dz;
     const int c2 = (((gz >> 1) + 1) * ny + ((gy >> 1) + 1)) * nx + ((gx >> 1) + 1);
-    const int b2 = start[c2];
-    if (start[c2 + 1] != b2) {
-      const int4 r = rec[b2 * 8 + ((gx & 1) | ((gy & 1) << 1) | ((gz & 1) << 2))];
+    oct[u] = (gx & 1) | ((gy & 1) << 1) | ((gz & 1) << 2);
+    b2[u] = e2[u] = 0;
+    if (k < 62 && s0 + u < m) {
+      b2[u] = start[c2];
+      e2[u] = start[c2 + 1];
+    }
+  }
+  int q0[kSubPerWave], n2[kSubPerWave], rep2[kSubPerWave];
+#pragma unroll
+  for (int u = 0; u < kSubPerWave; ++u) {
+    q0[u] = n2[u] = 0;
+    rep2[u] = -1;
+    if (e2[u] != b2[u]) {
+      const int4 r = rec[b2[u] * 8 + oct[u]];
       if (r.y > 0) {
-        q0 = r.x;
-        n2 = r.y;
-        rep2 = r.z;
+        q0[u] = r.x;
+        n2[u] = r.y;
+        rep2[u] = r.z;
       }
     }
   }
-  unsigned long long todo = __ballot(rep2 >= 0);
-  while (todo) {
-    const int src = __ffsll(todo) - 1;
-    todo &= todo - 1;
-    const int qb = __shfl(q0, src, 64), nb = __shfl(n2, src, 64), rb = __shfl(rep2, src, 64);
-    const int pairs = n1 * nb;
+  // the neighbours found here are pass 2's work list (one coalesced 256-byte row per
+  // sub-cell): it then starts two dependent loads further down the chain
+#pragma unroll
+  for (int u = 0; u < kSubPerWave; ++u)
+    if (s0 + u < m) nbr[size_t(s0 + u) * 64 + k] = rep2[u];
+#pragma unroll
+  for (int u = 0; u < kSubPerWave; ++u) {
+    const int p = me[u].x, n1 = me[u].w;
+    unsigned long long todo = __ballot(rep2[u] >= 0);
     bool found = false;
-    for (int base = 0; base < pairs && !found; base += 64) {
-      const int idx = base + k;
-      bool hit = false;
-      if (idx < pairs) {
-        const int a = p + idx / nb, q = qb + idx % nb;
-        hit = core[a] && core[q] && sqdist(sx[a], sy[a], sz[a], sx[q], sy[q], sz[q]) <= r2;
+    while (todo && !found) {
+      const int src = __ffsll(todo) - 1;
+      todo &= todo - 1;
+      const int qb = __shfl(q0[u], src, 64), nb = __shfl(n2[u], src, 64), rb = __shfl(rep2[u], src, 64);
+      const int pairs = n1 * nb;
+      for (int base = 0; base < pairs && !found; base += 64) {
+        const int idx = base + k;
+        bool hit = false;
+        if (idx < pairs) {
+          const int a = p + idx / nb, q = qb + idx % nb;
+          hit = core[a] && core[q] && sqdist(sx[a], sy[a], sz[a], sx[q], sy[q], sz[q]) <= r2;
+        }
+        found = __ballot(hit) != 0;
       }
-      found = __ballot(hit) != 0;
-    }
-    if (found) {
-      if (k == 0) parent[p] = rb;
-      return;
+      if (found && k == 0) parent[p] = rb;
     }
   }
 }
 
-// One WAVE per sub-cell with core points. Lane k < 62 looks at the k-th lexicographically
-// positive offset in [-2,2]^3 (every unordered pair of neighbouring sub-cells exactly once)
-// and decides whether that neighbour still has to be tested; then the wave takes the
-// neighbours that do one at a time and tests all |S1| x |S2| point pairs at once, 64 per
-// step. (A lane per pair of sub-cells running the pair loop itself was 3x slower: ~25
-// dependent iterations per lane, and a wave lasts as long as its slowest lane.)
-__global__ __launch_bounds__(256) void k_union_sub(const int4* __restrict__ list, int m, int k0,
-                                                   int k1, int nx, int ny,
-                                                   const int32_t* __restrict__ start,
+// Pass 2: a WAVE per kSubPerWave sub-cells with core points, over the same pairs (sub-cell, neighbour at
+// a lexicographically negative offset) that pass 1 resolved and left in `nbr` — every
+// unordered pair of neighbouring sub-cells exactly once. Lane k decides whether its
+// neighbour still has to be tested (after pass 1 and the compression almost none has: two
+// plain loads show the same root); the wave then takes the ones that do one at a time and
+// tests all |S1| x |S2| point pairs at once, 64 per step. (A lane per pair of sub-cells
+// running the pair loop itself was 3x slower: ~25 dependent iterations per lane, and a wave
+// lasts as long as its slowest lane.)
+__global__ __launch_bounds__(256) void k_union_sub(const int4* __restrict__ list, int m,
+                                                   const int32_t* __restrict__ nbr,
+                                                   const int32_t* __restrict__ sub_of,
                                                    const int4* __restrict__ rec,
                                                    const double* __restrict__ sx,
                                                    const double* __restrict__ sy,
                                                    const double* __restrict__ sz, double r2,
                                                    const uint8_t* __restrict__ core, int* parent) {
-  const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (s >= m) return;  // wave-uniform
+  const int s0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * kSubPerWave;
+  if (s0 >= m) return;  // wave-uniform
   const int k = threadIdx.x & 63;
-  const int4 me = list[s];
-  const int p = me.x, c1 = me.y, o1 = me.z & 7, n1 = me.w;
-  const int cx = c1 % nx, cy = (c1 / nx) % ny, cz = c1 / (nx * ny);
-  int q0 = 0, n2 = 0, rep2 = -1;
-  bool need = false;
-  if (k >= k0 && k < k1) {
-    const int dx = kSubOffsets[k][0], dy = kSubOffsets[k][1], dz = kSubOffsets[k][2];
-    // half-cell coordinates (cell 1 is the first interior cell; borders are empty)
-    const int gx = 2 * (cx - 1) + (o1 & 1) + dx, gy = 2 * (cy - 1) + ((o1 >> 1) & 1) + dy,
-              gz = 2 * (cz - 1) + ((o1 >> 2) & 1) + dz;
-    const int c2 = (((gz >> 1) + 1) * ny + ((gy >> 1) + 1)) * nx + ((gx >> 1) + 1);
-    const int b2 = start[c2];
-    if (start[c2 + 1] != b2) {
-      const int4 r = rec[b2 * 8 + ((gx & 1) | ((gy & 1) << 1) | ((gz & 1) << 2))];
-      if (r.y > 0) {
-        q0 = r.x;
-        n2 = r.y;
-        rep2 = r.z;
-      }
-    }
-    if (rep2 >= 0) {
-      // A plain (cached, possibly stale) read names an ancestor; equal ancestors prove
-      // "same tree" (trees only merge). The coherent chase is for the rest.
-      const volatile int* vparent = parent;
-      const int a1 = vparent[p], a2 = vparent[rep2];
-      need = !(a1 == a2 || a2 == p || a1 == rep2);
-      if (need) need = find_root(parent, rep2) != find_root(parent, p);
+  int rep2[kSubPerWave];
+  int4 me[kSubPerWave];
+#pragma unroll
+  for (int u = 0; u < kSubPerWave; ++u) {
+    rep2[u] = s0 + u < m ? nbr[size_t(s0 + u) * 64 + k] : -1;
+    me[u] = list[min(s0 + u, m - 1)];
+  }
+  // A plain (cached, possibly stale) read names an ancestor; equal ancestors prove
+  // "same tree" (trees only merge). The coherent chase is for the rest.
+  const int* vparent = parent;
+  int a1[kSubPerWave], a2[kSubPerWave];
+#pragma unroll
+  for (int u = 0; u < kSubPerWave; ++u) {
+    a1[u] = a2[u] = 0;
+    if (rep2[u] >= 0) {
+      a1[u] = vparent[me[u].x];
+      a2[u] = vparent[rep2[u]];
     }
   }
-  unsigned long long todo = __ballot(need);
-  while (todo) {
-    const int src = __ffsll(todo) - 1;
-    todo &= todo - 1;
-    const int qb = __shfl(q0, src, 64), nb = __shfl(n2, src, 64), rb = __shfl(rep2, src, 64);
-    const int pairs = n1 * nb;
-    bool found = false;
-    for (int base = 0; base < pairs && !found; base += 64) {
-      const int idx = base + k;
-      bool hit = false;
-      if (idx < pairs) {
-        const int a = p + idx / nb, q = qb + idx % nb;
-        hit = core[a] && core[q] && sqdist(sx[a], sy[a], sz[a], sx[q], sy[q], sz[q]) <= r2;
-      }
-      found = __ballot(hit) != 0;
+#pragma unroll
+  for (int u = 0; u < kSubPerWave; ++u) {
+    const int p = me[u].x, n1 = me[u].w;
+    bool need = rep2[u] >= 0 && !(a1[u] == a2[u] || a2[u] == p || a1[u] == rep2[u]);
+    if (need) need = find_root(parent, rep2[u]) != find_root(parent, p);
+    unsigned long long todo = __ballot(need);
+    if (!todo) continue;
+    int q0 = 0, n2 = 0;
+    if (need) {  // the neighbour's run: start and length
+      const int4 r = rec[sub_of[rep2[u]]];
+      q0 = r.x;
+      n2 = r.y;
     }
-    if (found && k == 0) unite(parent, p, rb);
+    while (todo) {
+      const int src = __ffsll(todo) - 1;
+      todo &= todo - 1;
+      const int qb = __shfl(q0, src, 64), nb = __shfl(n2, src, 64), rb = __shfl(rep2[u], src, 64);
+      const int pairs = n1 * nb;
+      bool found = false;
+      for (int base = 0; base < pairs && !found; base += 64) {
+        const int idx = base + k;
+        bool hit = false;
+        if (idx < pairs) {
+          const int a = p + idx / nb, q = qb + idx % nb;
+          hit = core[a] && core[q] && sqdist(sx[a], sy[a], sz[a], sx[q], sy[q], sz[q]) <= r2;
+        }
+        found = __ballot(hit) != 0;
+      }
+      if (found && k == 0) unite(parent, p, rb);
+    }
   }
 }
 
@@ -687,19 +725,21 @@ static int dbscan_device(Ctx* c, const double* xyz, int64_t n, double eps, int32
       PQ_HIP(hipMemcpyAsync(&m, list_cnt, 4, hipMemcpyDeviceToHost, c->stream));
       PQ_HIP(hipStreamSynchronize(c->stream));
       if (m > 0) {
-        const dim3 gw(ceil_div(m, 4)), gl(ceil_div(m, 256));
+        const dim3 gw(ceil_div(m, 4 * kSubPerWave)), gl(ceil_div(m, 256));
+        int32_t* nbr;  // [m][64] representatives of the neighbour sub-cells pass 1 resolved
+        PQ_TRY(c->arena.get(size_t(m) * 64, &nbr));
         {
           ProfScope pk(c, "k_hook_sub");
           hipLaunchKernelGGL(k_hook_sub, gw, block, 0, c->stream, list, m, g.nx, g.ny, g.start, sub.rec,
-                             g.sx, g.sy, g.sz, r2, core, parent);
+                             g.sx, g.sy, g.sz, r2, core, parent, nbr);
         }
         hipLaunchKernelGGL(k_flatten_reps, gl, block, 0, c->stream, list, m, parent);
         // what is left: joining the few trees per cluster. Almost every pair of neighbours
         // now shows the same root through two plain loads.
         {
           ProfScope pk(c, "k_union_sub");
-          hipLaunchKernelGGL(k_union_sub, gw, block, 0, c->stream, list, m, 0, 62, g.nx, g.ny, g.start,
-                             sub.rec, g.sx, g.sy, g.sz, r2, core, parent);
+          hipLaunchKernelGGL(k_union_sub, gw, block, 0, c->stream, list, m, nbr, sub.sub_of, sub.rec,
+                             g.sx, g.sy, g.sz, r2, core, parent);
         }
         hipLaunchKernelGGL(k_flatten_reps, gl, block, 0, c->stream, list, m, parent);
         hipLaunchKernelGGL(k_rep_min, gl, block, 0, c->stream, list, m, parent, run_min, min_orig);

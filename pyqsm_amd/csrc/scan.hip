@@ -1,6 +1,6 @@
 // scan.hip — device-wide exclusive prefix sum of int32 (three-phase: per-block
 // reduce, recursive scan of the block sums, per-block scan + offset). HBM-bound:
-// 2 reads + 1 write of the array.
+// 2 reads + 1 write of the array, all as whole cache lines per wave.
 #include "common.hpp"
 
 namespace pyqsm {
@@ -53,9 +53,54 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_reduce(const int32_t* __r
   if (threadIdx.x == 0) sums[blockIdx.x] = tot;
 }
 
+// Each thread owns two groups of four consecutive elements, one in each half of the tile,
+// loaded and stored as 16-byte vectors: a wave's access is 1 KB contiguous = 8 cache lines.
+// (Eight consecutive scalars per thread made every one of the 8 loads of a wave span 2 KB:
+// 128 line accesses for 16 lines of data, and 2.1 TB/s on a 16 M-cell grid.)
 __global__ __launch_bounds__(kScanThreads) void k_scan_apply(int32_t* __restrict__ data, int64_t n,
                                                              const int32_t* __restrict__ offs) {
-  // Each thread owns kScanItems consecutive elements of the tile.
+  const int64_t tile = int64_t(blockIdx.x) * kScanTile;
+  int4 v[2];
+  int32_t s[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int64_t i = tile + int64_t(j * kScanThreads + threadIdx.x) * 4;
+    if (i + 3 < n) {
+      v[j] = *reinterpret_cast<const int4*>(data + i);
+    } else {
+      v[j].x = i < n ? data[i] : 0;
+      v[j].y = i + 1 < n ? data[i + 1] : 0;
+      v[j].z = i + 2 < n ? data[i + 2] : 0;
+      v[j].w = 0;
+    }
+    s[j] = v[j].x + v[j].y + v[j].z + v[j].w;
+  }
+  int32_t tot0, tot1;
+  const int32_t r0 = block_excl_scan(s[0], &tot0);
+  const int32_t r1 = block_excl_scan(s[1], &tot1);
+  const int32_t off = offs ? offs[blockIdx.x] : 0;
+  const int32_t run[2] = {off + r0, off + tot0 + r1};
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int64_t i = tile + int64_t(j * kScanThreads + threadIdx.x) * 4;
+    int4 o;
+    o.x = run[j];
+    o.y = o.x + v[j].x;
+    o.z = o.y + v[j].y;
+    o.w = o.z + v[j].z;
+    if (i + 3 < n) {
+      *reinterpret_cast<int4*>(data + i) = o;
+    } else {
+      if (i < n) data[i] = o.x;
+      if (i + 1 < n) data[i + 1] = o.y;
+      if (i + 2 < n) data[i + 2] = o.z;
+    }
+  }
+}
+
+// the same for arrays that do not start on a 16-byte boundary
+__global__ __launch_bounds__(kScanThreads) void k_scan_apply_unaligned(int32_t* __restrict__ data, int64_t n,
+                                                                       const int32_t* __restrict__ offs) {
   const int64_t base = int64_t(blockIdx.x) * kScanTile + int64_t(threadIdx.x) * kScanItems;
   int32_t v[kScanItems];
   int32_t s = 0;
@@ -73,12 +118,19 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_apply(int32_t* __restrict
   }
 }
 
+static void launch_apply(Ctx* c, int64_t nb, int32_t* data, int64_t n, const int32_t* offs) {
+  if ((reinterpret_cast<uintptr_t>(data) & 15) == 0)
+    hipLaunchKernelGGL(k_scan_apply, dim3(unsigned(nb)), dim3(kScanThreads), 0, c->stream, data, n, offs);
+  else
+    hipLaunchKernelGGL(k_scan_apply_unaligned, dim3(unsigned(nb)), dim3(kScanThreads), 0, c->stream, data, n,
+                       offs);
+}
+
 int exclusive_scan_i32(Ctx* c, int32_t* data, int64_t n) {
   if (n <= 0) return 0;
   const int64_t nb = (n + kScanTile - 1) / kScanTile;
   if (nb == 1) {
-    hipLaunchKernelGGL(k_scan_apply, dim3(1), dim3(kScanThreads), 0, c->stream, data, n,
-                       static_cast<const int32_t*>(nullptr));
+    launch_apply(c, 1, data, n, nullptr);
     PQ_HIP(hipGetLastError());
     return 0;
   }
@@ -88,8 +140,7 @@ int exclusive_scan_i32(Ctx* c, int32_t* data, int64_t n) {
                      sums);
   PQ_HIP(hipGetLastError());
   PQ_TRY(exclusive_scan_i32(c, sums, nb));
-  hipLaunchKernelGGL(k_scan_apply, dim3(unsigned(nb)), dim3(kScanThreads), 0, c->stream, data, n,
-                     sums);
+  launch_apply(c, nb, data, n, sums);
   PQ_HIP(hipGetLastError());
   return 0;
 }
