@@ -321,12 +321,6 @@ __global__ __launch_bounds__(256) void k_rows_to_csr(int nc, const int32_t* __re
 
 // ---- cycle kernels (fp32) ----------------------------------------------------------
 
-__global__ __launch_bounds__(256) void k_to_float(int64_t n, const double* __restrict__ a,
-                                                  float* __restrict__ out) {
-  int64_t i = blockIdx.x * int64_t(256) + threadIdx.x;
-  if (i < n) out[i] = float(a[i]);
-}
-
 // vals, 1/l1 as float
 __global__ __launch_bounds__(256) void k_level_floats(int n, const int32_t* __restrict__ indptr,
                                                       const double* __restrict__ vals,
@@ -339,6 +333,43 @@ __global__ __launch_bounds__(256) void k_level_floats(int n, const int32_t* __re
   dinvf[i] = float(dinv[i]);
 }
 
+// The cycle's fp32 vectors hold one float4 (x, y, z, 0) per row: a neighbour's entry is ONE
+// 16-byte gather instead of three 4-byte ones. These kernels are bound by the number of
+// cache lines their gathers touch (the L1 takes a divergent access a line at a time), and
+// three gathers at the same columns touch the same lines three times.
+__device__ __forceinline__ float4 ld4(const float* v, int i) {
+  return reinterpret_cast<const float4*>(v)[i];
+}
+__device__ __forceinline__ void st4(float* v, int i, float a, float b, float c) {
+  reinterpret_cast<float4*>(v)[i] = make_float4(a, b, c, 0.f);
+}
+
+// rows of a caller-side vector: float4 for fp32, three doubles for fp64
+__device__ __forceinline__ void ld_row(const float* v, int i, float& a, float& b, float& c) {
+  const float4 t = ld4(v, i);
+  a = t.x;
+  b = t.y;
+  c = t.z;
+}
+__device__ __forceinline__ void ld_row(const double* v, int i, double& a, double& b, double& c) {
+  a = v[3 * i];
+  b = v[3 * i + 1];
+  c = v[3 * i + 2];
+}
+__device__ __forceinline__ void st_row(float* v, int i, float a, float b, float c) { st4(v, i, a, b, c); }
+__device__ __forceinline__ void st_row(double* v, int i, float a, float b, float c) {
+  v[3 * i] = double(a);
+  v[3 * i + 1] = double(b);
+  v[3 * i + 2] = double(c);
+}
+
+// A thread walks its row kRowUnroll entries at a time with the loads of a chunk issued side by
+// side: one entry at a time is two dependent memory latencies per entry (index, then the
+// gather), ~14 per row, and at 1 M rows there are only two waves per slot to hide them
+// behind. Entries past the row's end read the row itself with weight 0 (adds +0: the sums
+// keep their bits).
+static constexpr int kRowUnroll = 8;
+
 // pre-smoothing from a zero start fused with the residual:
 //   x = Dinv b ;  r = b - A x
 __global__ __launch_bounds__(256) void k_down(int n, const int32_t* __restrict__ indptr,
@@ -350,21 +381,33 @@ __global__ __launch_bounds__(256) void k_down(int n, const int32_t* __restrict__
   int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-  for (int j = indptr[i]; j < indptr[i + 1]; ++j) {
-    const int col = indices[j];
-    const float v = vals[j] * dinv[col];
-    a0 += v * b[3 * col];
-    a1 += v * b[3 * col + 1];
-    a2 += v * b[3 * col + 2];
+  const int e = indptr[i + 1];
+  for (int j = indptr[i]; j < e; j += kRowUnroll) {
+    int col[kRowUnroll];
+    float v[kRowUnroll];
+    float4 bc[kRowUnroll];
+#pragma unroll
+    for (int u = 0; u < kRowUnroll; ++u) {  // past the row's end: the row itself, weight 0
+      const bool ok = j + u < e;
+      col[u] = ok ? indices[j + u] : i;
+      v[u] = ok ? vals[j + u] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < kRowUnroll; ++u) {
+      v[u] *= dinv[col[u]];
+      bc[u] = ld4(b, col[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < kRowUnroll; ++u) {
+      a0 += v[u] * bc[u].x;
+      a1 += v[u] * bc[u].y;
+      a2 += v[u] * bc[u].z;
+    }
   }
   const float d = dinv[i];
-  const float b0 = b[3 * i], b1 = b[3 * i + 1], b2 = b[3 * i + 2];
-  x[3 * i] = d * b0;
-  x[3 * i + 1] = d * b1;
-  x[3 * i + 2] = d * b2;
-  r[3 * i] = b0 - a0;
-  r[3 * i + 1] = b1 - a1;
-  r[3 * i + 2] = b2 - a2;
+  const float4 bi = ld4(b, i);
+  st4(x, i, d * bi.x, d * bi.y, d * bi.z);
+  st4(r, i, bi.x - a0, bi.y - a1, bi.z - a2);
 }
 
 // rc[a] = sum of r over the members of aggregate a
@@ -375,15 +418,22 @@ __global__ __launch_bounds__(256) void k_restrict(int nc, const int32_t* __restr
   int a = blockIdx.x * 256 + threadIdx.x;
   if (a >= nc) return;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-  for (int m = mptr[a]; m < mptr[a + 1]; ++m) {
-    const int i = members[m];
-    s0 += r[3 * i];
-    s1 += r[3 * i + 1];
-    s2 += r[3 * i + 2];
+  const int e = mptr[a + 1];
+  for (int m = mptr[a]; m < e; m += kRowUnroll) {
+    int idx[kRowUnroll];
+    float4 t[kRowUnroll];
+#pragma unroll
+    for (int u = 0; u < kRowUnroll; ++u) idx[u] = m + u < e ? members[m + u] : -1;
+#pragma unroll
+    for (int u = 0; u < kRowUnroll; ++u) t[u] = idx[u] >= 0 ? ld4(r, idx[u]) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < kRowUnroll; ++u) {
+      s0 += t[u].x;
+      s1 += t[u].y;
+      s2 += t[u].z;
+    }
   }
-  rc[3 * a] = s0;
-  rc[3 * a + 1] = s1;
-  rc[3 * a + 2] = s2;
+  st4(rc, a, s0, s1, s2);
 }
 
 // coarse correction fused with the post-smoothing sweep:
@@ -405,37 +455,56 @@ __global__ __launch_bounds__(256) void k_up(int n, const int32_t* __restrict__ i
   // grid-stride: with a dot product the launch is capped (the atomics that end it are per block)
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-    for (int j = indptr[i]; j < indptr[i + 1]; ++j) {
-      const int col = indices[j];
-      const float v = vals[j];
-      const int ac = agg[col];
-      float y0 = x[3 * col], y1 = x[3 * col + 1], y2 = x[3 * col + 2];
-      if (ac >= 0) {
-        y0 += xc[3 * ac];
-        y1 += xc[3 * ac + 1];
-        y2 += xc[3 * ac + 2];
+    const int e = indptr[i + 1];
+    for (int j = indptr[i]; j < e; j += kRowUnroll) {
+      int col[kRowUnroll], ac[kRowUnroll];
+      float v[kRowUnroll];
+      float4 xv[kRowUnroll], c4[kRowUnroll];
+#pragma unroll
+      for (int u = 0; u < kRowUnroll; ++u) {  // past the row's end: the row itself, weight 0
+        const bool ok = j + u < e;
+        col[u] = ok ? indices[j + u] : i;
+        v[u] = ok ? vals[j + u] : 0.f;
       }
-      a0 += v * y0;
-      a1 += v * y1;
-      a2 += v * y2;
+#pragma unroll
+      for (int u = 0; u < kRowUnroll; ++u) {
+        ac[u] = agg[col[u]];
+        xv[u] = ld4(x, col[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < kRowUnroll; ++u) c4[u] = ac[u] >= 0 ? ld4(xc, ac[u]) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int u = 0; u < kRowUnroll; ++u) {
+        float y0 = xv[u].x, y1 = xv[u].y, y2 = xv[u].z;
+        if (ac[u] >= 0) {
+          y0 += c4[u].x;
+          y1 += c4[u].y;
+          y2 += c4[u].z;
+        }
+        a0 += v[u] * y0;
+        a1 += v[u] * y1;
+        a2 += v[u] * y2;
+      }
     }
     const int ai = agg[i];
-    float y0 = x[3 * i], y1 = x[3 * i + 1], y2 = x[3 * i + 2];
+    const float4 xi = ld4(x, i);
+    float y0 = xi.x, y1 = xi.y, y2 = xi.z;
     if (ai >= 0) {
-      y0 += xc[3 * ai];
-      y1 += xc[3 * ai + 1];
-      y2 += xc[3 * ai + 2];
+      const float4 c4 = ld4(xc, ai);
+      y0 += c4.x;
+      y1 += c4.y;
+      y2 += c4.z;
     }
     const float d = dinv[i];
-    const float o0 = y0 + d * (b[3 * i] - a0), o1 = y1 + d * (b[3 * i + 1] - a1),
-                o2 = y2 + d * (b[3 * i + 2] - a2);
-    out[3 * i] = TO(o0);
-    out[3 * i + 1] = TO(o1);
-    out[3 * i + 2] = TO(o2);
+    const float4 bi = ld4(b, i);
+    const float o0 = y0 + d * (bi.x - a0), o1 = y1 + d * (bi.y - a1), o2 = y2 + d * (bi.z - a2);
+    st_row(out, i, o0, o1, o2);
     if (bd) {
-      d0 += double(bd[3 * i]) * double(o0);
-      d1 += double(bd[3 * i + 1]) * double(o1);
-      d2 += double(bd[3 * i + 2]) * double(o2);
+      TBD e0, e1, e2;
+      ld_row(bd, i, e0, e1, e2);
+      d0 += double(e0) * double(o0);
+      d1 += double(e1) * double(o1);
+      d2 += double(e2) * double(o2);
     }
   }
   if (dot) reduce3_atomic(d0, d1, d2, dot);
@@ -451,17 +520,29 @@ __global__ __launch_bounds__(256) void k_sweep(int n, const int32_t* __restrict_
   int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-  for (int j = indptr[i]; j < indptr[i + 1]; ++j) {
-    const int col = indices[j];
-    const float v = vals[j];
-    a0 += v * x[3 * col];
-    a1 += v * x[3 * col + 1];
-    a2 += v * x[3 * col + 2];
+  const int e = indptr[i + 1];
+  for (int j = indptr[i]; j < e; j += kRowUnroll) {
+    int col[kRowUnroll];
+    float v[kRowUnroll];
+    float4 xv[kRowUnroll];
+#pragma unroll
+    for (int u = 0; u < kRowUnroll; ++u) {
+      const bool ok = j + u < e;
+      col[u] = ok ? indices[j + u] : i;
+      v[u] = ok ? vals[j + u] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < kRowUnroll; ++u) xv[u] = ld4(x, col[u]);
+#pragma unroll
+    for (int u = 0; u < kRowUnroll; ++u) {
+      a0 += v[u] * xv[u].x;
+      a1 += v[u] * xv[u].y;
+      a2 += v[u] * xv[u].z;
+    }
   }
   const float d = dinv[i];
-  out[3 * i] = x[3 * i] + d * (b[3 * i] - a0);
-  out[3 * i + 1] = x[3 * i + 1] + d * (b[3 * i + 1] - a1);
-  out[3 * i + 2] = x[3 * i + 2] + d * (b[3 * i + 2] - a2);
+  const float4 xi = ld4(x, i), bi = ld4(b, i);
+  st4(out, i, xi.x + d * (bi.x - a0), xi.y + d * (bi.y - a1), xi.z + d * (bi.z - a2));
 }
 
 // x = dinv .* b
@@ -470,8 +551,8 @@ __global__ __launch_bounds__(256) void k_scale(int n, const float* __restrict__ 
   int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const float d = dinv[i];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) x[3 * i + k] = d * b[3 * i + k];
+  const float4 bi = ld4(b, i);
+  st4(x, i, d * bi.x, d * bi.y, d * bi.z);
 }
 
 // x = Ainv * b on the coarsest level (nc <= kCoarseMax), one block; the inverse stays fp64
@@ -479,23 +560,31 @@ __global__ __launch_bounds__(128) void k_dense_solve(int nc, const double* __res
                                                      const float* __restrict__ b,
                                                      float* __restrict__ x) {
   __shared__ double sb[kCoarseMax * 3];
-  for (int t = threadIdx.x; t < nc * 3; t += blockDim.x) sb[t] = double(b[t]);
+  for (int t = threadIdx.x; t < nc * 3; t += blockDim.x) sb[t] = double(b[kVecStride * (t / 3) + t % 3]);
   __syncthreads();
   for (int t = threadIdx.x; t < nc * 3; t += blockDim.x) {
     const int i = t / 3, k = t % 3;
     double s = 0.0;
     for (int j = 0; j < nc; ++j) s += ainv[size_t(i) * nc + j] * sb[3 * j + k];
-    x[t] = float(s);
+    x[kVecStride * i + k] = float(s);
   }
+  for (int i = threadIdx.x; i < nc; i += blockDim.x) x[kVecStride * i + 3] = 0.f;
+}
+
+// fp64 [n,3] -> the cycle's fp32 rows
+__global__ __launch_bounds__(256) void k_rows_to_float(int n, const double* __restrict__ a,
+                                                       float* __restrict__ out) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) st4(out, i, float(a[3 * i]), float(a[3 * i + 1]), float(a[3 * i + 2]));
 }
 
 // ---- host side ------------------------------------------------------------------------
 
 static int alloc_vectors(Ctx* c, AmgLevel& L, bool coarse, int nnz) {
-  PQ_TRY(c->arena.get(size_t(L.n) * 3, &L.r));
-  PQ_TRY(c->arena.get(size_t(L.n) * 3, &L.xa));
-  PQ_TRY(c->arena.get(size_t(L.n) * 3, &L.b));  // level 0: the fp32 copy of the right-hand side
-  if (coarse) PQ_TRY(c->arena.get(size_t(L.n) * 3, &L.xb));
+  PQ_TRY(c->arena.get(size_t(L.n) * kVecStride, &L.r));
+  PQ_TRY(c->arena.get(size_t(L.n) * kVecStride, &L.xa));
+  PQ_TRY(c->arena.get(size_t(L.n) * kVecStride, &L.b));  // level 0: the fp32 copy of the right-hand side
+  if (coarse) PQ_TRY(c->arena.get(size_t(L.n) * kVecStride, &L.xb));
   PQ_TRY(c->arena.get(size_t(nnz) + 1, &L.valsf));
   PQ_TRY(c->arena.get(size_t(L.n), &L.dinvf));
   hipLaunchKernelGGL(k_level_floats, dim3(ceil_div(L.n, 256)), dim3(256), 0, c->stream, L.n, L.A.indptr,
@@ -719,8 +808,7 @@ static int vcycle_impl(Ctx* c, AmgHierarchy* H, const TV* b, TV* x, double* dot)
   AmgLevel& L0 = H->lv[0];
   const float* b0 = nullptr;
   if constexpr (std::is_same<TV, double>::value) {  // the cycle works on an fp32 copy
-    hipLaunchKernelGGL(k_to_float, dim3(ceil_div(int64_t(L0.n) * 3, 256)), blk, 0, c->stream,
-                       int64_t(L0.n) * 3, b, L0.b);
+    hipLaunchKernelGGL(k_rows_to_float, dim3(ceil_div(L0.n, 256)), blk, 0, c->stream, L0.n, b, L0.b);
     b0 = L0.b;
   } else {
     b0 = b;

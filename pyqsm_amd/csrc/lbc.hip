@@ -607,6 +607,15 @@ struct WorkF {
   Scal* sc;
 };
 
+__device__ __forceinline__ float4 ld4(const float* v, int i) {
+  return reinterpret_cast<const float4*>(v)[i];
+}
+__device__ __forceinline__ void st4(float* v, int i, float a, float b, float c) {
+  reinterpret_cast<float4*>(v)[i] = make_float4(a, b, c, 0.f);
+}
+
+static constexpr int kU = 8;
+
 __global__ __launch_bounds__(256) void k_bspmv_f(int n, const int32_t* __restrict__ indptr,
                                                  const int32_t* __restrict__ indices,
                                                  const float* __restrict__ vals,
@@ -619,19 +628,31 @@ __global__ __launch_bounds__(256) void k_bspmv_f(int n, const int32_t* __restric
   // address are served one at a time (4000 blocks cost ~40 us of a 70 us kernel)
   for (int i = gid; i < n; i += gridDim.x * 256) {
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-    for (int j = indptr[i]; j < indptr[i + 1]; ++j) {
-      const int col = indices[j];
-      const float v = vals[j];
-      a0 += v * p[3 * col];
-      a1 += v * p[3 * col + 1];
-      a2 += v * p[3 * col + 2];
+    const int e = indptr[i + 1];
+    for (int j = indptr[i]; j < e; j += kU) {  // kU entries' loads side by side (amg.hip: kRowUnroll)
+      int col[kU];
+      float v[kU];
+      float4 pc[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const bool ok = j + u < e;
+        col[u] = ok ? indices[j + u] : i;
+        v[u] = ok ? vals[j + u] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < kU; ++u) pc[u] = ld4(p, col[u]);
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        a0 += v[u] * pc[u].x;
+        a1 += v[u] * pc[u].y;
+        a2 += v[u] * pc[u].z;
+      }
     }
-    q[3 * i] = a0;
-    q[3 * i + 1] = a1;
-    q[3 * i + 2] = a2;
-    pq[0] += double(p[3 * i]) * a0;
-    pq[1] += double(p[3 * i + 1]) * a1;
-    pq[2] += double(p[3 * i + 2]) * a2;
+    st4(q, i, a0, a1, a2);
+    const float4 pi = ld4(p, i);
+    pq[0] += double(pi.x) * a0;
+    pq[1] += double(pi.y) * a1;
+    pq[2] += double(pi.z) * a2;
   }
   reduce3_atomic(pq[0], pq[1], pq[2], sc->pq[par]);
 }
@@ -648,13 +669,13 @@ __global__ __launch_bounds__(256) void k_update_r_f(int n, const float* __restri
     alpha[k] = float(pqk != 0.0 ? sc->rz[par][k] / pqk : 0.0);
   }
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      x[3 * i + k] += alpha[k] * dir[3 * i + k];
-      const float ri = r[3 * i + k] - alpha[k] * q[3 * i + k];
-      r[3 * i + k] = ri;
-      rr[k] += double(ri) * ri;
-    }
+    const float4 d = ld4(dir, i), qi = ld4(q, i), xi = ld4(x, i), ri = ld4(r, i);
+    st4(x, i, xi.x + alpha[0] * d.x, xi.y + alpha[1] * d.y, xi.z + alpha[2] * d.z);
+    const float r0 = ri.x - alpha[0] * qi.x, r1 = ri.y - alpha[1] * qi.y, r2 = ri.z - alpha[2] * qi.z;
+    st4(r, i, r0, r1, r2);
+    rr[0] += double(r0) * r0;
+    rr[1] += double(r1) * r1;
+    rr[2] += double(r2) * r2;
   }
   reduce3_atomic(rr[0], rr[1], rr[2], sc->rr[par]);
 }
@@ -668,34 +689,43 @@ __global__ __launch_bounds__(256) void k_direction_f(int n, const float* __restr
     sc->rr[par ^ 1][i] = 0.0;
   }
   if (i >= n) return;
+  float beta[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     const double rzk = sc->rz[par][k];
-    const float beta = float(rzk != 0.0 ? sc->rz[par ^ 1][k] / rzk : 0.0);
-    dir[3 * i + k] = z[3 * i + k] + beta * dir[3 * i + k];
+    beta[k] = float(rzk != 0.0 ? sc->rz[par ^ 1][k] / rzk : 0.0);
   }
+  const float4 zi = ld4(z, i), d = ld4(dir, i);
+  st4(dir, i, zi.x + beta[0] * d.x, zi.y + beta[1] * d.y, zi.z + beta[2] * d.z);
 }
 
 __global__ __launch_bounds__(256) void k_dot3_f(int n, const float* __restrict__ a,
                                                 double* __restrict__ out) {
   double d[3] = {0, 0, 0};
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-#pragma unroll
-    for (int k = 0; k < 3; ++k) d[k] += double(a[3 * i + k]) * a[3 * i + k];
+    const float4 t = ld4(a, i);
+    d[0] += double(t.x) * t.x;
+    d[1] += double(t.y) * t.y;
+    d[2] += double(t.z) * t.z;
   }
   reduce3_atomic(d[0], d[1], d[2], out);
 }
 
-__global__ __launch_bounds__(256) void k_cvt_d2f(int64_t n, const double* __restrict__ a,
+// fp64 [n,3] <-> fp32 rows of kVecStride floats
+__global__ __launch_bounds__(256) void k_cvt_d2f(int n, const double* __restrict__ a,
                                                  float* __restrict__ out) {
-  int64_t i = blockIdx.x * int64_t(256) + threadIdx.x;
-  if (i < n) out[i] = float(a[i]);
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) st4(out, i, float(a[3 * i]), float(a[3 * i + 1]), float(a[3 * i + 2]));
 }
 
-__global__ __launch_bounds__(256) void k_cvt_f2d(int64_t n, const float* __restrict__ a,
+__global__ __launch_bounds__(256) void k_cvt_f2d(int n, const float* __restrict__ a,
                                                  double* __restrict__ out) {
-  int64_t i = blockIdx.x * int64_t(256) + threadIdx.x;
-  if (i < n) out[i] = double(a[i]);
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float4 t = ld4(a, i);
+  out[3 * i] = double(t.x);
+  out[3 * i + 1] = double(t.y);
+  out[3 * i + 2] = double(t.z);
 }
 
 // y = B^-1 rhs to rtol, everything fp32 (rhs and y are float [n,3]); y starts at 0.
@@ -707,12 +737,12 @@ static int amg_pcg_f32(Ctx* c, int N, const WorkF& w, AmgHierarchy* H, const flo
   const float* bv;
   amg_fine_matrix(H, &ip, &ix, &bv);
   PQ_HIP(hipMemsetAsync(w.sc, 0, sizeof(Scal), c->stream));
-  PQ_HIP(hipMemsetAsync(y, 0, size_t(N) * 12, c->stream));
-  PQ_HIP(hipMemcpyAsync(w.r, rhs, size_t(N) * 12, hipMemcpyDeviceToDevice, c->stream));
+  PQ_HIP(hipMemsetAsync(y, 0, size_t(N) * kVecStride * 4, c->stream));
+  PQ_HIP(hipMemcpyAsync(w.r, rhs, size_t(N) * kVecStride * 4, hipMemcpyDeviceToDevice, c->stream));
   const dim3 rgrid(unsigned(std::min<int64_t>(ceil_div(N, 256), kReduceBlocks)));  // kernels that end in atomics
   hipLaunchKernelGGL(k_dot3_f, rgrid, block, 0, c->stream, N, rhs, w.sc->bb);
   PQ_TRY(amg_vcycle_f32(c, H, w.r, w.z, w.sc->rz[0]));
-  PQ_HIP(hipMemcpyAsync(w.dir, w.z, size_t(N) * 12, hipMemcpyDeviceToDevice, c->stream));
+  PQ_HIP(hipMemcpyAsync(w.dir, w.z, size_t(N) * kVecStride * 4, hipMemcpyDeviceToDevice, c->stream));
   for (int k = 0; k < 3; ++k) resid[k] = 1.0;
   *iters = 0;
   auto iteration = [&](int par) -> int {
@@ -856,13 +886,13 @@ static int lbc_solve_core(Ctx* c, const DevCsr& L, int64_t n, const double* wl, 
   WorkF wf{nullptr, nullptr, nullptr, nullptr, nullptr};
   float *f_rhs = nullptr, *f_y = nullptr, *f_out = nullptr;
   if (use_f32) {
-    PQ_TRY(c->arena.get(size_t(n) * 3, &wf.r));
-    PQ_TRY(c->arena.get(size_t(n) * 3, &wf.z));
-    PQ_TRY(c->arena.get(size_t(n) * 3, &wf.dir));
-    PQ_TRY(c->arena.get(size_t(n) * 3, &wf.q));
-    PQ_TRY(c->arena.get(size_t(n) * 3, &f_rhs));
-    PQ_TRY(c->arena.get(size_t(n) * 3, &f_y));
-    PQ_TRY(c->arena.get(size_t(n) * 3, &f_out));
+    PQ_TRY(c->arena.get(size_t(n) * kVecStride, &wf.r));
+    PQ_TRY(c->arena.get(size_t(n) * kVecStride, &wf.z));
+    PQ_TRY(c->arena.get(size_t(n) * kVecStride, &wf.dir));
+    PQ_TRY(c->arena.get(size_t(n) * kVecStride, &wf.q));
+    PQ_TRY(c->arena.get(size_t(n) * kVecStride, &f_rhs));
+    PQ_TRY(c->arena.get(size_t(n) * kVecStride, &f_y));
+    PQ_TRY(c->arena.get(size_t(n) * kVecStride, &f_out));
     wf.sc = wb.sc;
   }
   // max_it caps the total number of inner (sparse-pass) iterations
@@ -871,8 +901,7 @@ static int lbc_solve_core(Ctx* c, const DevCsr& L, int64_t n, const double* wl, 
     int32_t it1 = 0, it2 = 0;
     double rs[3];
     if (amg && use_f32) {
-      const dim3 g3(ceil_div(n * 3, 256));
-      hipLaunchKernelGGL(k_cvt_d2f, g3, block, 0, c->stream, n * 3, rhs, f_rhs);
+      hipLaunchKernelGGL(k_cvt_d2f, grid, block, 0, c->stream, N, rhs, f_rhs);
       int rc = amg_pcg_f32(c, N, wf, amg, f_rhs, f_y, kInnerRtol, std::min(budget(), kAmgMaxIt), &cache, &it1,
                            rs);
       if (rc != 0 && rc != PYQSM_ENOCONV) return rc;
@@ -880,7 +909,7 @@ static int lbc_solve_core(Ctx* c, const DevCsr& L, int64_t n, const double* wl, 
       rc = amg_pcg_f32(c, N, wf, amg, f_y, f_out, kInnerRtol, std::min(budget(), kAmgMaxIt), &cache, &it2, rs);
       if (rc != 0 && rc != PYQSM_ENOCONV) return rc;
       total_inner += it2;
-      hipLaunchKernelGGL(k_cvt_f2d, g3, block, 0, c->stream, n * 3, f_out, out);
+      hipLaunchKernelGGL(k_cvt_f2d, grid, block, 0, c->stream, N, f_out, out);
       return 0;
     }
     if (amg) {

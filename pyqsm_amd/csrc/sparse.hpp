@@ -46,8 +46,11 @@ int amg_levels(const AmgHierarchy* h);
 // piecewise-constant strength-based aggregation, dense solve on the coarsest level).
 // When `dot` is given, dot[0..2] += b . x per column (fused into the last kernel).
 int amg_vcycle(Ctx* c, AmgHierarchy* h, const double* b, double* x, double* dot = nullptr);
-// The same with fp32 vectors (no conversion pass), and the fp32 copy of B the cycle uses on its
-// finest level (for a CG that runs in fp32 altogether).
+// Floats per row of an fp32 solver vector: (x, y, z, 0), so that a row is one 16-byte access.
+static constexpr int kVecStride = 4;
+
+// The same with fp32 vectors of kVecStride floats per row (no conversion pass), and the fp32
+// copy of B the cycle uses on its finest level (for a CG that runs in fp32 altogether).
 int amg_vcycle_f32(Ctx* c, AmgHierarchy* h, const float* b, float* x, double* dot = nullptr);
 void amg_fine_matrix(const AmgHierarchy* h, const int32_t** indptr, const int32_t** indices,
                      const float** vals);
