@@ -1093,7 +1093,10 @@ int lbc_solve_device(Ctx* c, const DevCsr& L, int64_t n, const double* wl, doubl
     return lbc_solve_core(c, L, n, wl, wl_uniform, wh, pts, rtol, max_it, x, iters, resid);
   const int N = int(n);
   const dim3 grid(ceil_div(n, 256)), grid1(ceil_div(n + 1, 256)), block(256);
-  // cells of ~1/128 of the extent (the dense grid is capped at 2^24 cells)
+  // cells of ~1/512 of the extent (the dense grid is capped at 2^24 cells; the edge doubles to
+  // fit). Finer cells = neighbours closer in memory: 1/128 -> 1/512 took 10 % off an iteration;
+  // numbering the cells block by block (8^3) instead of row by row changed nothing, and so did
+  // staging the CSR segments of 64 rows through LDS — what is left is the gathers themselves.
   double mn[3], mx[3];
   PQ_TRY(cloud_bbox(c, pts, n, mn, mx));
   double ext = std::max(mx[0] - mn[0], std::max(mx[1] - mn[1], mx[2] - mn[2]));
@@ -1101,7 +1104,7 @@ int lbc_solve_device(Ctx* c, const DevCsr& L, int64_t n, const double* wl, doubl
     return lbc_solve_core(c, L, n, wl, wl_uniform, wh, pts, rtol, max_it, x, iters, resid);
   double box[6] = {mn[0], mn[1], mn[2], mx[0], mx[1], mx[2]};
   DevGrid g;
-  PQ_TRY(build_grid(c, pts, n, ext / 128.0, int64_t(1) << 24, &g, box));
+  PQ_TRY(build_grid(c, pts, n, ext / 512.0, int64_t(1) << 24, &g, box));
   int32_t nnz = 0;
   PQ_HIP(hipMemcpyAsync(&nnz, L.indptr + n, 4, hipMemcpyDeviceToHost, c->stream));
   PQ_HIP(hipStreamSynchronize(c->stream));
