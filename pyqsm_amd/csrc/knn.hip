@@ -148,7 +148,7 @@ __global__ __launch_bounds__(T) void k_knn(int n_query, const int32_t* __restric
 
 
 // Level-0 search for k <= 32: the same per-lane shell walk, but the sorted best-K list lives
-// in REGISTERS (K = k rounded up to 8/16/24/32; unrolled, branch-free insertion) instead
+// in REGISTERS (K = k rounded up to a multiple of 4; unrolled, branch-free insertion) instead
 // of a 12*k-byte LDS column per lane. At k = 20 the LDS columns allow two blocks per CU
 // (two waves per SIMD) and the walk is a chain of dependent gathers: occupancy is what it
 // needs. Slots beyond k only make the acceptance test slightly more generous.
@@ -470,14 +470,18 @@ int knn_device(Ctx* c, const double* xyz, int64_t n, int32_t k, int32_t exclude_
       ProfScope ps(c, level == 0 ? "knn_search" : "knn_retry");
       int32_t* fl = (level & 1) ? fail_b : fail_a;
       if (level == 0 && k <= 32) {
-        if (k <= 8)
-          PQ_TRY(launch_knn_reg<8>(c, N, g, k, exclude_self, last, idx, d2, fl, fail_count));
-        else if (k <= 16)
-          PQ_TRY(launch_knn_reg<16>(c, N, g, k, exclude_self, last, idx, d2, fl, fail_count));
-        else if (k <= 24)
-          PQ_TRY(launch_knn_reg<24>(c, N, g, k, exclude_self, last, idx, d2, fl, fail_count));
-        else
-          PQ_TRY(launch_knn_reg<32>(c, N, g, k, exclude_self, last, idx, d2, fl, fail_count));
+        // list length = k rounded up to a multiple of 4: every slot is ~11 instructions per
+        // insertion, and slots beyond k loosen the acceptance test
+        switch ((k + 3) / 4) {
+          case 1: PQ_TRY(launch_knn_reg<4>(c, N, g, k, exclude_self, last, idx, d2, fl, fail_count)); break;
+          case 2: PQ_TRY(launch_knn_reg<8>(c, N, g, k, exclude_self, last, idx, d2, fl, fail_count)); break;
+          case 3: PQ_TRY(launch_knn_reg<12>(c, N, g, k, exclude_self, last, idx, d2, fl, fail_count)); break;
+          case 4: PQ_TRY(launch_knn_reg<16>(c, N, g, k, exclude_self, last, idx, d2, fl, fail_count)); break;
+          case 5: PQ_TRY(launch_knn_reg<20>(c, N, g, k, exclude_self, last, idx, d2, fl, fail_count)); break;
+          case 6: PQ_TRY(launch_knn_reg<24>(c, N, g, k, exclude_self, last, idx, d2, fl, fail_count)); break;
+          case 7: PQ_TRY(launch_knn_reg<28>(c, N, g, k, exclude_self, last, idx, d2, fl, fail_count)); break;
+          default: PQ_TRY(launch_knn_reg<32>(c, N, g, k, exclude_self, last, idx, d2, fl, fail_count)); break;
+        }
       } else if (level > 0 && k <= 64) {
         KnnGrid kg{g.nx, g.ny, g.nz, g.cell};
         hipLaunchKernelGGL(k_knn_wave, dim3(ceil_div(n_query, 4)), dim3(256), 0, c->stream, n_query,
