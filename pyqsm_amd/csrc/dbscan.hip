@@ -417,7 +417,11 @@ __global__ __launch_bounds__(256) void k_hook_sub(const int4* __restrict__ list,
         }
         found = __ballot(hit) != 0;
       }
-      if (found && k == 0) parent[p] = rb;
+      // Hang under the neighbour's own pointer rather than under the neighbour: sub-cells are
+      // listed in spatial order, the smaller neighbour's wave has usually finished, and what
+      // it points to is an ancestor still smaller than this sub-cell (no cycles). Chains come
+      // out a few links long instead of as long as a trunk is tall in sub-cells.
+      if (found && k == 0) parent[p] = parent[rb];
     }
   }
 }
