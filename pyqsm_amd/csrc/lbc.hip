@@ -33,7 +33,9 @@ static constexpr int kStallIters = 1500;
 // close to its attainable accuracy
 static constexpr double kStallBelow = 1e-8;
 
-// y = L (s .* x)   three columns; one lane per row (rows hold ~14 entries).
+static constexpr int kRowChunk = 4;
+
+// y = L (s .* x)   three columns; one lane per row (rows hold ~7 entries).
 __global__ __launch_bounds__(256) void k_spmv3(int n, const int32_t* __restrict__ indptr,
                                                const int32_t* __restrict__ indices,
                                                const double* __restrict__ vals,
@@ -44,13 +46,30 @@ __global__ __launch_bounds__(256) void k_spmv3(int n, const int32_t* __restrict_
   if (i >= n) return;
   double a0 = 0.0, a1 = 0.0, a2 = 0.0;
   const int b = indptr[i], e = indptr[i + 1];
-  for (int j = b; j < e; ++j) {
-    const int col = indices[j];
-    double v = vals[j];
-    if (s) v *= s[col];
-    a0 += v * x[3 * col];
-    a1 += v * x[3 * col + 1];
-    a2 += v * x[3 * col + 2];
+  // four entries at a time, their loads issued side by side (amg.hip: kRowUnroll); entries
+  // past the row's end read the row itself with weight 0
+  for (int j = b; j < e; j += kRowChunk) {
+    int col[kRowChunk];
+    double v[kRowChunk], x0[kRowChunk], x1[kRowChunk], x2[kRowChunk];
+#pragma unroll
+    for (int u = 0; u < kRowChunk; ++u) {
+      const bool ok = j + u < e;
+      col[u] = ok ? indices[j + u] : i;
+      v[u] = ok ? vals[j + u] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < kRowChunk; ++u) {
+      if (s) v[u] *= s[col[u]];
+      x0[u] = x[3 * col[u]];
+      x1[u] = x[3 * col[u] + 1];
+      x2[u] = x[3 * col[u] + 2];
+    }
+#pragma unroll
+    for (int u = 0; u < kRowChunk; ++u) {
+      a0 += v[u] * x0[u];
+      a1 += v[u] * x1[u];
+      a2 += v[u] * x2[u];
+    }
   }
   y[3 * i] = a0;
   y[3 * i + 1] = a1;
@@ -130,12 +149,27 @@ __global__ __launch_bounds__(256) void k_spmv3_tail(int n, const int32_t* __rest
   if (i < n) {
     double a0 = 0.0, a1 = 0.0, a2 = 0.0;
     const int b = indptr[i], e = indptr[i + 1];
-    for (int j = b; j < e; ++j) {
-      const int col = indices[j];
-      const double v = vals[j];
-      a0 += v * x[3 * col];
-      a1 += v * x[3 * col + 1];
-      a2 += v * x[3 * col + 2];
+    for (int j = b; j < e; j += kRowChunk) {
+      int col[kRowChunk];
+      double v[kRowChunk], x0[kRowChunk], x1[kRowChunk], x2[kRowChunk];
+#pragma unroll
+      for (int u = 0; u < kRowChunk; ++u) {
+        const bool ok = j + u < e;
+        col[u] = ok ? indices[j + u] : i;
+        v[u] = ok ? vals[j + u] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < kRowChunk; ++u) {
+        x0[u] = x[3 * col[u]];
+        x1[u] = x[3 * col[u] + 1];
+        x2[u] = x[3 * col[u] + 2];
+      }
+#pragma unroll
+      for (int u = 0; u < kRowChunk; ++u) {
+        a0 += v[u] * x0[u];
+        a1 += v[u] * x1[u];
+        a2 += v[u] * x2[u];
+      }
     }
     const double a = OP == OP_A ? wl[i] : c;
     const double h = OP == OP_A ? wh[i] * wh[i] : wh[i];

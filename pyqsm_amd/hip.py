@@ -7,6 +7,7 @@ No computation happens in Python here.
 from __future__ import annotations
 
 import ctypes
+import weakref
 
 import numpy as np
 
@@ -384,6 +385,14 @@ def fps(points, num_samples: int, start_index: int = 0, device: int = 0) -> np.n
 
 # ---------------------------------------------------------------- Laplacian
 
+def _adopt(lib, ptr, ctype, count: int, dtype):
+    """NumPy array over a buffer the library malloc'ed; the buffer is released with
+    ``pyqsm_free`` once the array and every view of it are gone."""
+    buf = (ctype * count).from_address(ptr.value)
+    weakref.finalize(buf, lib.pyqsm_free, ctypes.c_void_p(ptr.value))
+    return np.frombuffer(buf, dtype=dtype, count=count)
+
+
 def pc_laplacian(points, k: int = 30, moll: float = 1e-5, device: int = 0):
     """(indptr, indices, data) CSR triple and lumped mass [n]."""
     pts = _points(points)
@@ -395,14 +404,9 @@ def pc_laplacian(points, k: int = 30, moll: float = 1e-5, device: int = 0):
     check(lib.pyqsm_pc_laplacian(_p(pts), n, int(k), float(moll), ctypes.byref(nnz),
                                  ctypes.byref(ip), ctypes.byref(ix), ctypes.byref(dv), _p(mass),
                                  int(device)))
-    try:
-        indptr = np.ctypeslib.as_array(ctypes.cast(ip, ctypes.POINTER(ctypes.c_int32)),
-                                       (n + 1,)).copy()
-        indices = np.ctypeslib.as_array(ctypes.cast(ix, ctypes.POINTER(ctypes.c_int32)),
-                                        (max(nnz.value, 1),))[:nnz.value].copy()
-        data = np.ctypeslib.as_array(ctypes.cast(dv, ctypes.POINTER(ctypes.c_double)),
-                                     (max(nnz.value, 1),))[:nnz.value].copy()
-    finally:
-        for q in (ip, ix, dv):
-            lib.pyqsm_free(q)
+    # the library's malloc'ed outputs become the NumPy arrays themselves (91 MB per million points
+    # that are not copied again); pyqsm_free runs when the last view of a buffer is gone
+    indptr = _adopt(lib, ip, ctypes.c_int32, n + 1, np.int32)
+    indices = _adopt(lib, ix, ctypes.c_int32, max(nnz.value, 1), np.int32)[:nnz.value]
+    data = _adopt(lib, dv, ctypes.c_double, max(nnz.value, 1), np.float64)[:nnz.value]
     return (indptr, indices, data), mass
