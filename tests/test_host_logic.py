@@ -171,3 +171,36 @@ def test_label_grouping_equals_the_reference_loop():
         assert list(ul) == list(ul2)
         assert len(idxs) == len(idxs2) and all(np.array_equal(a, b) for a, b in zip(idxs, idxs2))
         assert np.array_equal(np.asarray(noise), np.asarray(noise2))
+
+
+def test_adopted_buffers_are_released_after_the_last_view():
+    """hip._adopt wraps a malloc'ed output of the library in a NumPy array without copying;
+    the buffer must live as long as ANY view of it and be released exactly once."""
+    import ctypes
+    import gc
+
+    from pyqsm_amd import hip
+
+    libc = ctypes.CDLL(None)
+    libc.malloc.restype = ctypes.c_void_p
+    libc.malloc.argtypes = [ctypes.c_size_t]
+    libc.free.argtypes = [ctypes.c_void_p]
+    freed = []
+
+    class FakeLib:
+        @staticmethod
+        def pyqsm_free(p):
+            freed.append(p.value)
+            libc.free(p)
+
+    raw = libc.malloc(10 * 4)
+    ptr = ctypes.c_void_p(raw)
+    arr = hip._adopt(FakeLib, ptr, ctypes.c_int32, 10, np.int32)
+    arr[:] = np.arange(10)
+    view = arr[3:7]
+    del arr
+    gc.collect()
+    assert freed == [] and view.tolist() == [3, 4, 5, 6]
+    del view
+    gc.collect()
+    assert freed == [raw]
