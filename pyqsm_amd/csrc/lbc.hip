@@ -384,6 +384,13 @@ static bool graphs_enabled() {
   return !getenv("PYQSM_NO_GRAPH") && !getenv("ROCP_TOOL_LIBRARIES");
 }
 
+// The multigrid-CG bursts are plain launches unless PYQSM_AMG_GRAPH is set: their graphs hold
+// 30-150 kernel nodes, are instantiated anew for every B-solve pair and replayed ~5 times, and
+// measured against plain launches they lose at every size on this ROCm (20 contractions:
+// 1 M points 5.28 vs 5.07 s, 50 k 0.82 vs 0.77 s, 5 k 0.61 vs 0.55 s). They paid off for
+// the round's first solver — 24-iteration bursts of four tiny kernels — which keeps them.
+static bool amg_graphs_enabled() { return getenv("PYQSM_AMG_GRAPH") && graphs_enabled(); }
+
 // A burst of kBurst CG iterations recorded once as a hipGraph and replayed: at a
 // few thousand points an iteration is four ~5 us launches, and replaying a graph
 // costs about a third of launching them one by one.
@@ -568,7 +575,7 @@ static int amg_pcg(Ctx* c, const System& S, const Work& w, AmgHierarchy* H, cons
     hipLaunchKernelGGL(k_direction, grid, block, 0, c->stream, N, w.z, w.dir, w.sc, par);
     return 0;
   };
-  if (!graphs_enabled()) cache = nullptr;
+  if (!amg_graphs_enabled()) cache = nullptr;
   // graphs are keyed by (hierarchy, target vector, burst length)
   auto run_burst = [&](int len) -> int {
     hipGraphExec_t exec = nullptr;
@@ -786,7 +793,7 @@ static int amg_pcg_f32(Ctx* c, int N, const WorkF& w, AmgHierarchy* H, const flo
     hipLaunchKernelGGL(k_direction_f, grid, block, 0, c->stream, N, w.z, w.dir, w.sc, par);
     return 0;
   };
-  if (!graphs_enabled()) cache = nullptr;
+  if (!amg_graphs_enabled()) cache = nullptr;
   auto run_burst = [&](int len) -> int {
     hipGraphExec_t exec = nullptr;
     if (cache)
