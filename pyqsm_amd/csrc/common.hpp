@@ -17,6 +17,14 @@
 namespace pyqsm {
 
 void set_error(const char* fmt, ...);
+
+// Host buffers the library hands to its caller (released with pyqsm_free). Buffers of a
+// megabyte or more come page-locked from a small pool (context.hip): the device-to-host copy
+// into them, and the host-to-device copy when the caller passes them back (the Laplacian goes
+// straight into the contraction solve), run at link speed instead of through the driver's
+// staging of pageable memory. Falls back to malloc; nullptr when that fails too.
+void* out_alloc(size_t bytes);
+void out_free(void* p);
 int fail(int code, const char* fmt, ...);
 
 #define PQ_HIP(expr)                                                                   \

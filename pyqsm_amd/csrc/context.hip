@@ -72,6 +72,65 @@ void Arena::destroy() {
   chunks_.clear();
 }
 
+// ---- page-locked output buffers ----------------------------------------------------------
+// Page-locking is slow (~10 ms per 100 MB), so released buffers are kept and handed out again:
+// the contraction loop asks for the same three sizes every step. At most kPinnedIdleCap bytes
+// sit idle; beyond that, and for small requests, plain malloc.
+static constexpr size_t kPinnedMin = size_t(1) << 20;
+static constexpr size_t kPinnedIdleCap = size_t(2) << 30;
+static std::mutex g_pin_mu;
+static std::multimap<size_t, void*>& pin_idle() {
+  static auto* m = new std::multimap<size_t, void*>();
+  return *m;
+}
+static std::map<void*, size_t>& pin_live() {
+  static auto* m = new std::map<void*, size_t>();
+  return *m;
+}
+static size_t g_pin_idle_bytes = 0;
+
+void* out_alloc(size_t bytes) {
+  if (bytes >= kPinnedMin) {
+    const size_t want = (bytes + kPinnedMin - 1) / kPinnedMin * kPinnedMin;
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    auto it = pin_idle().lower_bound(want);
+    if (it != pin_idle().end() && it->first <= want + want / 4) {  // at most 25 % larger than asked
+      void* p = it->second;
+      g_pin_idle_bytes -= it->first;
+      pin_live()[p] = it->first;
+      pin_idle().erase(it);
+      return p;
+    }
+    void* p = nullptr;
+    if (hipHostMalloc(&p, want, hipHostMallocDefault) == hipSuccess && p) {
+      pin_live()[p] = want;
+      return p;
+    }
+    (void)hipGetLastError();  // not fatal: pageable memory does the job
+  }
+  return malloc(bytes ? bytes : 1);
+}
+
+void out_free(void* p) {
+  if (!p) return;
+  {
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    auto it = pin_live().find(p);
+    if (it != pin_live().end()) {
+      const size_t sz = it->second;
+      pin_live().erase(it);
+      if (g_pin_idle_bytes + sz <= kPinnedIdleCap) {
+        pin_idle().emplace(sz, p);
+        g_pin_idle_bytes += sz;
+      } else {
+        (void)hipHostFree(p);
+      }
+      return;
+    }
+  }
+  free(p);
+}
+
 // ---- contexts -----------------------------------------------------------
 
 // One context (stream + scratch arena + timers) per device AND calling thread, so that
@@ -215,6 +274,12 @@ int pyqsm_shutdown(void) {
   }
   pools().clear();
   ++g_generation;
+  {
+    std::lock_guard<std::mutex> lk2(g_pin_mu);
+    for (auto& kv : pin_idle()) (void)hipHostFree(kv.second);
+    pin_idle().clear();
+    g_pin_idle_bytes = 0;
+  }
   return 0;
 }
 
@@ -269,7 +334,7 @@ int pyqsm_d2h(int device, void* dst, const void* src, size_t bytes) {
   return 0;
 }
 
-void pyqsm_free(void* p) { free(p); }
+void pyqsm_free(void* p) { out_free(p); }
 
 int pyqsm_prof_enable(int device, int on) {
   Ctx* c = ctx_for(device);

@@ -821,7 +821,7 @@ int pyqsm_pc_laplacian(const double* xyz, int64_t n, int32_t k, double moll, int
   if (!c) return PYQSM_ENODEV;
   std::lock_guard<std::mutex> lk(c->mu);
   c->arena.reset();
-  int32_t* h_indptr = static_cast<int32_t*>(malloc((size_t(n) + 1) * 4));
+  int32_t* h_indptr = static_cast<int32_t*>(out_alloc((size_t(n) + 1) * 4));
   if (!h_indptr) return fail(PYQSM_ENOMEM, "host allocation failed");
   if (n == 0) {
     h_indptr[0] = 0;
@@ -996,11 +996,11 @@ int pyqsm_pc_laplacian(const double* xyz, int64_t n, int32_t k, double moll, int
     hipLaunchKernelGGL(k_rows, gn, blk, 0, c->stream, N, d_vcount, d_ent, d_area, d_nnzrow, d_indices,
                        d_vals, d_mass);
     PQ_HIP(hipGetLastError());
-    int32_t* h_indices = static_cast<int32_t*>(malloc((size_t(nnz) + 1) * 4));
-    double* h_vals = static_cast<double*>(malloc((size_t(nnz) + 1) * 8));
+    int32_t* h_indices = static_cast<int32_t*>(out_alloc((size_t(nnz) + 1) * 4));
+    double* h_vals = static_cast<double*>(out_alloc((size_t(nnz) + 1) * 8));
     if (!h_indices || !h_vals) {
-      free(h_indices);
-      free(h_vals);
+      out_free(h_indices);
+      out_free(h_vals);
       return fail(PYQSM_ENOMEM, "host allocation failed");
     }
     *indices_out = h_indices;
@@ -1015,9 +1015,9 @@ int pyqsm_pc_laplacian(const double* xyz, int64_t n, int32_t k, double moll, int
   };
   rc = body();
   if (rc != 0) {
-    free(h_indptr);
-    free(*indices_out);
-    free(*vals_out);
+    out_free(h_indptr);
+    out_free(*indices_out);
+    out_free(*vals_out);
     *indices_out = nullptr;
     *vals_out = nullptr;
     return rc;
