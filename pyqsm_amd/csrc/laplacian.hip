@@ -119,19 +119,27 @@ __host__ __device__ inline double pseudo_angle(double x, double y) {
 
 __device__ __forceinline__ double bcast(double v, int lane) { return __shfl(v, lane, 64); }
 
+// PER = points per wave: 1 (64 lanes for up to 64 neighbours) or 2 (a half-wave of 32 lanes
+// each, for k <= 32 — with pyQSM's 30 neighbours a whole wave per point leaves 34 lanes idle
+// through three k-step loops of fp64 arithmetic). Lane s of a group holds neighbour s; a
+// broadcast "from neighbour l" reads lane (group base + l).
+template <int PER>
 __global__ __launch_bounds__(256) void k_fans(int n, int k, const double* __restrict__ xyz,
                                               const int32_t* __restrict__ nbr,
                                               int32_t* __restrict__ tri /*[n*k][2]*/,
                                               int32_t* __restrict__ tri_count /*[n]*/) {
+  constexpr int G = 64 / PER;  // lanes per point
   __shared__ int32_t sorted[4][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int i = blockIdx.x * 4 + w;
-  if (i >= n) return;  // whole wave exits together
-  const double px = xyz[3 * i], py = xyz[3 * i + 1], pz = xyz[3 * i + 2];
+  const int grp = lane / G, sub = lane % G, gbase = grp * G;
+  const int i = (blockIdx.x * 4 + w) * PER + grp;
+  const bool live = i < n;  // (the second half of the last wave may have no point)
+  const int ic = live ? i : n - 1;
+  const double px = xyz[3 * ic], py = xyz[3 * ic + 1], pz = xyz[3 * ic + 2];
   int nb = n;
   double dx = 0.0, dy = 0.0, dz = 0.0;
-  if (lane < k) {
-    nb = nbr[size_t(i) * k + lane];
+  if (live && sub < k) {
+    nb = nbr[size_t(i) * k + sub];
     if (nb < n) {
       dx = xyz[3 * nb] - px;
       dy = xyz[3 * nb + 1] - py;
@@ -139,10 +147,10 @@ __global__ __launch_bounds__(256) void k_fans(int n, int k, const double* __rest
     }
   }
   const bool valid = nb < n;
-  // covariance of the offsets, accumulated in neighbour order (every lane the same)
+  // covariance of the offsets, accumulated in neighbour order (every lane of the group the same)
   Sym3 A = {0, 0, 0, 0, 0, 0};
   for (int l = 0; l < k; ++l) {
-    const double x = bcast(dx, l), y = bcast(dy, l), z = bcast(dz, l);
+    const double x = bcast(dx, gbase + l), y = bcast(dy, gbase + l), z = bcast(dz, gbase + l);
     A.a00 += x * x;
     A.a01 += x * y;
     A.a02 += x * z;
@@ -160,9 +168,9 @@ __global__ __launch_bounds__(256) void k_fans(int n, int k, const double* __rest
   double lo = -__builtin_inf(), hi = __builtin_inf();
   bool blocked = !valid || uu == 0.0;
   for (int l = 0; l < k; ++l) {
-    const double ul = bcast(u, l), vl = bcast(v, l);
-    const int vl_ok = __shfl(int(valid), l, 64);
-    if (l == lane || !vl_ok) continue;
+    const double ul = bcast(u, gbase + l), vl = bcast(v, gbase + l);
+    const int vl_ok = __shfl(int(valid), gbase + l, 64);
+    if (l == sub || !vl_ok) continue;
     const double cr = u * vl - v * ul;
     const double b = ((ul * ul + vl * vl) - (u * ul + v * vl)) * 0.5;
     if (cr > 0.0) {
@@ -180,27 +188,29 @@ __global__ __launch_bounds__(256) void k_fans(int n, int k, const double* __rest
   // rank among the kept neighbours by (angle, lane)
   int rank = 0, m = 0;
   for (int l = 0; l < k; ++l) {
-    const double al = bcast(ang, l);
-    const int nl = __shfl(int(nat), l, 64);
+    const double al = bcast(ang, gbase + l);
+    const int nl = __shfl(int(nat), gbase + l, 64);
     if (!nl) continue;
     ++m;
-    if (al < ang || (al == ang && l < lane)) ++rank;
+    if (al < ang || (al == ang && l < sub)) ++rank;
   }
-  if (nat) sorted[w][rank] = lane;
+  if (nat) sorted[w][gbase + rank] = sub;
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the LDS writes above have landed
-  int succ = lane;
-  if (nat && m >= 2) succ = sorted[w][rank + 1 == m ? 0 : rank + 1];
-  const double us = bcast(u, succ), vs = bcast(v, succ);
-  const int nbs = __shfl(nb, succ, 64);
-  const bool emit = nat && m >= 2 && (u * vs - v * us) > 0.0 && nbs != nb;
-  const unsigned long long mask = __ballot(emit);
+  int succ = sub;
+  if (nat && m >= 2) succ = sorted[w][gbase + (rank + 1 == m ? 0 : rank + 1)];
+  const double us = bcast(u, gbase + succ), vs = bcast(v, gbase + succ);
+  const int nbs = __shfl(nb, gbase + succ, 64);
+  const bool emit = live && nat && m >= 2 && (u * vs - v * us) > 0.0 && nbs != nb;
+  const unsigned long long all = __ballot(emit);
+  const unsigned long long gmask = PER == 1 ? ~0ull : (0xFFFFFFFFull << gbase);
+  const unsigned long long mask = all & gmask;
   if (emit) {
     const int slot = __popcll(mask & ((1ull << lane) - 1ull));
     tri[(size_t(i) * k + slot) * 2] = nb;
     tri[(size_t(i) * k + slot) * 2 + 1] = nbs;
   }
-  if (lane == 0) tri_count[i] = __popcll(mask);
+  if (live && sub == 0) tri_count[i] = __popcll(mask);
 }
 
 // ---- stage 3/4: triangle list -> lengths, eps, weights ---------------------------
@@ -850,8 +860,12 @@ int pyqsm_pc_laplacian(const double* xyz, int64_t n, int32_t k, double moll, int
     PQ_HIP(hipMemsetAsync(d_tcount, 0, (size_t(n) + 1) * 4, c->stream));
     {
       ProfScope ps(c, "lap_fans");
-      hipLaunchKernelGGL(k_fans, dim3(ceil_div(n, 4)), dim3(256), 0, c->stream, N, k, d_xyz, d_nbr,
-                         d_tri, d_tcount);
+      if (k <= 32)
+        hipLaunchKernelGGL(k_fans<2>, dim3(ceil_div(n, 8)), dim3(256), 0, c->stream, N, k, d_xyz, d_nbr, d_tri,
+                           d_tcount);
+      else
+        hipLaunchKernelGGL(k_fans<1>, dim3(ceil_div(n, 4)), dim3(256), 0, c->stream, N, k, d_xyz, d_nbr, d_tri,
+                           d_tcount);
       PQ_HIP(hipGetLastError());
     }
     ProfScope ps(c, "lap_assemble");
