@@ -62,10 +62,9 @@ def main():
     out["mean_contraction_m"] = shifts
 
     t0 = time.perf_counter()
-    fits = 0
-    radii = []
-    for tree in idxs[: max(args.max_trees, 4)]:
+    def fit_slices(tree):
         cloud = pts[tree]
+        found = []
         for z0 in np.arange(0.5, 5.5, 0.5):                 # 0.5 m slices of the stem
             sl = cloud[(cloud[:, 2] >= z0) & (cloud[:, 2] < z0 + 0.5)]
             sl = sl[np.hypot(sl[:, 0] - np.median(sl[:, 0]), sl[:, 1] - np.median(sl[:, 1])) < 0.6]
@@ -75,8 +74,12 @@ def main():
             mesh, _, inl, r, axis = fit_shape_RANSAC(pts=sl.copy(), shape="circle", threshold=0.04,
                                                      max_radius=0.3 * 1.75, samples=samples)
             if mesh is not None:
-                fits += 1
-                radii.append(float(r))
+                found.append(float(r))
+        return found
+
+    with ThreadPoolExecutor(max_workers=max(1, args.workers)) as pool:
+        radii = [r for found in pool.map(fit_slices, idxs[: max(args.max_trees, 4)]) for r in found]
+    fits = len(radii)
     out["ransac_s"] = time.perf_counter() - t0
     out["ransac_fits"] = fits
     out["ransac_median_radius_m"] = float(np.median(radii)) if radii else None
