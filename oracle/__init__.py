@@ -138,6 +138,34 @@ def cast_rays(verts, tris, rays):
     return t_hit, prim, uv
 
 
+
+def interception_layers(verts, tris, rays, max_rounds=None):
+    """data/notes/methods.md:53-55 ("metrics with overlap"): cast, sum the area of the
+    triangles hit first, remove them, repeat until nothing is hit. The reference keeps no
+    code for it (parity with the reference unpinned); this restates the procedure with the
+    oracle's own closest-hit sweep. Returns (areas per round, round of every triangle)."""
+    v = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 3)
+    t = np.ascontiguousarray(tris, dtype=np.int32).reshape(-1, 3)
+    e1 = v[t[:, 1]].astype(np.float64) - v[t[:, 0]].astype(np.float64)
+    e2 = v[t[:, 2]].astype(np.float64) - v[t[:, 0]].astype(np.float64)
+    tri_area = 0.5 * np.linalg.norm(np.cross(e1, e2), axis=1)
+    layer = np.full(len(t), -1, dtype=np.int64)
+    areas = []
+    alive = np.arange(len(t))
+    rnd = 0
+    while len(alive) and len(np.asarray(rays).reshape(-1, 6)) and (max_rounds is None or rnd < max_rounds):
+        _, prim, _ = cast_rays(v, t[alive], rays)
+        hit = np.unique(prim[prim != np.uint32(0xFFFFFFFF)])
+        if len(hit) == 0:
+            break
+        ids = alive[hit]
+        layer[ids] = rnd
+        areas.append(float(tri_area[ids].sum()))
+        alive = np.delete(alive, hit)
+        rnd += 1
+    return areas, layer
+
+
 def point_mesh_distance(verts, tris, queries):
     """(dist f32 [Q], prim u32 [Q]): unsigned distance to the mesh, closest triangle."""
     v = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 3)

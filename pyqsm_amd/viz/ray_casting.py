@@ -254,3 +254,49 @@ def get_points_inside_mesh(mesh, query_pts, device: int = 0) -> np.ndarray:
     scene = RaycastingScene(device)
     scene.add_triangles(mesh)
     return scene.compute_occupancy(query_pts)
+
+
+def interception_layers(mesh, rays, max_rounds=None, device: int = 0):
+    """The "metrics with overlap" of data/notes/methods.md:53-55: cast the rays, sum the area of
+    the triangles that intercept them first, remove those triangles, and repeat until no ray
+    hits anything (or ``max_rounds`` is reached). The reference describes the procedure and
+    keeps no code for it; this is its straightforward reading (``oracle.interception_layers``
+    restates it on the CPU; parity with the reference itself is unpinned).
+
+    Returns ``(areas, layer)``: ``areas[r]`` is the summed area (float64, from the float32
+    vertices) of the triangles removed in round r, ``layer[t]`` the round in which triangle t
+    was removed (-1: never hit). The rays stay in HBM for all rounds; each round uploads the
+    surviving triangles, sweeps (``pyqsm_cast_rays_dev``) and reads back the primitive ids."""
+    verts, tris = mesh_arrays(mesh)
+    r = np.ascontiguousarray(np.asarray(rays), dtype=np.float32).reshape(-1, 6)
+    R, T = r.shape[0], tris.shape[0]
+    e1 = verts[tris[:, 1]].astype(np.float64) - verts[tris[:, 0]].astype(np.float64)
+    e2 = verts[tris[:, 2]].astype(np.float64) - verts[tris[:, 0]].astype(np.float64)
+    tri_area = 0.5 * np.linalg.norm(np.cross(e1, e2), axis=1)
+    layer = np.full(T, -1, dtype=np.int64)
+    areas = []
+    if R == 0 or T == 0:
+        return areas, layer
+    alive = np.arange(T)
+    d_rays = hip.DeviceBuffer.from_array(r, device)
+    d_t = hip.DeviceBuffer(R * 4, device)
+    d_prim = hip.DeviceBuffer(R * 4, device)
+    try:
+        rnd = 0
+        while len(alive) and (max_rounds is None or rnd < max_rounds):
+            dm = hip.DeviceMesh(verts, tris[alive], device)
+            hip.cast_rays_dev(dm, d_rays.ptr, R, d_t.ptr, d_prim.ptr)
+            prim = d_prim.download((R,), np.uint32)          # synchronises
+            dm.records.free()
+            hit = np.unique(prim[prim != hip.MISS_PRIM])
+            if len(hit) == 0:
+                break
+            ids = alive[hit]
+            layer[ids] = rnd
+            areas.append(float(tri_area[ids].sum()))
+            alive = np.delete(alive, hit)
+            rnd += 1
+    finally:
+        for b in (d_rays, d_t, d_prim):
+            b.free()
+    return areas, layer

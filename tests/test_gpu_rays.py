@@ -187,3 +187,31 @@ def test_randomised_cameras_and_sun_angles(gpu):
         rays = synth.sun_rays(verts, 30_000, elevation_deg=float(rng.uniform(5, 89)),
                               azimuth_deg=float(rng.uniform(0, 360)))
         _check(verts, tris, rays, gpu)
+
+
+def test_interception_layers_peel_a_canopy(gpu):
+    """Cast, remove what was hit first, repeat (data/notes/methods.md:53-55): rounds, areas and
+    the round of every triangle equal the CPU restatement; a stack of three parallel sheets
+    under vertical rays comes off sheet by sheet."""
+    from pyqsm_amd.viz.ray_casting import interception_layers
+
+    verts, tris = synth.canopy_mesh(6000)
+    rays = synth.sun_rays(verts, 40_000, elevation_deg=60.0, azimuth_deg=135.0)
+    areas, layer = interception_layers((verts, tris), rays, device=gpu)
+    want_areas, want_layer = oracle.interception_layers(verts, tris, rays)
+    assert np.array_equal(layer, want_layer)
+    assert areas == want_areas
+    assert len(areas) >= 3 and (layer == 0).sum() > (layer == 2).sum() > 0
+
+    # three unit squares (two triangles each) at z = 0, 1, 2; rays straight down from z = 5
+    sq = np.array([[0, 0], [1, 0], [1, 1], [0, 1]], dtype=np.float32)
+    v = np.concatenate([np.c_[sq, np.full(4, z, np.float32)] for z in (0.0, 1.0, 2.0)])
+    t = np.concatenate([np.array([[0, 1, 2], [0, 2, 3]]) + 4 * k for k in range(3)]).astype(np.int32)
+    gx, gy = np.meshgrid(np.linspace(0.05, 0.95, 10), np.linspace(0.05, 0.95, 10))
+    r = np.zeros((100, 6), dtype=np.float32)
+    r[:, 0], r[:, 1], r[:, 2], r[:, 5] = gx.ravel(), gy.ravel(), 5.0, -1.0
+    areas, layer = interception_layers((v, t), r, device=gpu)
+    assert areas == [1.0, 1.0, 1.0]
+    assert layer.tolist() == [2, 2, 1, 1, 0, 0]
+    areas, layer = interception_layers((v, t), r, max_rounds=1, device=gpu)
+    assert areas == [1.0] and layer.tolist() == [-1, -1, -1, -1, 0, 0]

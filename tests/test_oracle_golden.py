@@ -127,3 +127,18 @@ def test_point_mesh_distance_known_answers():
     q = np.array([[-1, -1, 0], [0.5, -2, 0], [0.25, 0.25, 3], [2, 2, 0]], np.float32)
     d, _ = oracle.point_mesh_distance(tv, tt, q)
     assert np.allclose(d, [np.sqrt(2), 2.0, 3.0, np.sqrt(4.5)], rtol=1e-6)
+
+
+def test_interception_layers_three_sheets():
+    """The cast / remove / repeat metric of data/notes/methods.md:53-55 (no reference code:
+    parity unpinned) on a case with a known answer: three unit sheets under vertical rays."""
+    sq = np.array([[0, 0], [1, 0], [1, 1], [0, 1]], dtype=np.float32)
+    v = np.concatenate([np.c_[sq, np.full(4, z, np.float32)] for z in (0.0, 1.0, 2.0)])
+    t = np.concatenate([np.array([[0, 1, 2], [0, 2, 3]]) + 4 * k for k in range(3)]).astype(np.int32)
+    gx, gy = np.meshgrid(np.linspace(0.05, 0.95, 10), np.linspace(0.05, 0.95, 10))
+    r = np.zeros((100, 6), dtype=np.float32)
+    r[:, 0], r[:, 1], r[:, 2], r[:, 5] = gx.ravel(), gy.ravel(), 5.0, -1.0
+    areas, layer = oracle.interception_layers(v, t, r)
+    assert areas == [1.0, 1.0, 1.0] and layer.tolist() == [2, 2, 1, 1, 0, 0]
+    areas, layer = oracle.interception_layers(v, t, r[:0])
+    assert areas == [] and (layer == -1).all()
