@@ -288,7 +288,9 @@ def interception_layers(mesh, rays, max_rounds=None, device: int = 0):
             hip.cast_rays_dev(dm, d_rays.ptr, R, d_t.ptr, d_prim.ptr)
             prim = d_prim.download((R,), np.uint32)          # synchronises
             dm.records.free()
-            hit = np.unique(prim[prim != hip.MISS_PRIM])
+            mark = np.zeros(len(alive) + 1, dtype=bool)       # (np.unique would sort 10^7 ids)
+            mark[np.minimum(prim, len(alive))] = True        # misses (0xFFFFFFFF) land in the spare slot
+            hit = np.flatnonzero(mark[:-1])
             if len(hit) == 0:
                 break
             ids = alive[hit]
