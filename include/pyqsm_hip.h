@@ -186,11 +186,12 @@ int pyqsm_ransac_count(const double* pts, int64_t n, const double* models, int64
  * gradient over 3 right-hand sides that never forms L'L.
  *   L as CSR (indptr i32 [n+1], indices i32 [nnz], vals f64 [nnz]);
  *   wl, wh, f64 [n]; pts f64 [n,3] (also the start vector); out f64 [n,3]
- *   uniform wl (what extract_skeleton produces): flexible CG preconditioned by
- *   B^-2, B = c L + W_H; stops when the preconditioned residual |B^-2 r| / |x|,
- *   an estimate of the relative error of x (B^-2 A has its spectrum in [1/2, 1]
- *   for uniform W_H), is <= rtol for every coordinate; non-uniform wl: Jacobi-CG,
- *   stops when |r|/|b| <= rtol. Also stops after max_it sparse passes or when
+ *   positive wl that is constant along every edge of L (uniform, as extract_skeleton
+ *   produces it, or one value per connected block of a block-diagonal L): flexible
+ *   CG preconditioned by B^-2, B = W_L L + W_H; stops when the preconditioned
+ *   residual |B^-2 r| / |x|, an estimate of the relative error of x (B^-2 A has
+ *   its spectrum in [1/2, 1] for uniform W_H), is <= rtol for every coordinate;
+ *   any other wl: Jacobi-CG, stops when |r|/|b| <= rtol. Also stops after max_it sparse passes or when
  *   the estimate has stopped improving (attainable accuracy); in those two cases
  *   returns PYQSM_ENOCONV with the best iterate in `out`. `resid` always receives
  *   the true relative residuals |r|/|b| of the returned iterate.

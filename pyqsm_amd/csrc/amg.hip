@@ -87,16 +87,19 @@ __global__ __launch_bounds__(256) void k_diag_l1(int n, const int32_t* __restric
   dinv[i] = s > 0.0 ? 1.0 / s : 1.0;
 }
 
-// B = c*L + diag(wh) as an explicit CSR copy (same pattern as L: L stores its diagonal)
+// B = diag(cw) L + diag(wh) as an explicit CSR copy (same pattern as L: L stores its diagonal);
+// cw is constant along every edge of L, which keeps B symmetric
 __global__ __launch_bounds__(256) void k_make_b(int n, const int32_t* __restrict__ indptr,
                                                 const int32_t* __restrict__ indices,
-                                                const double* __restrict__ lvals, double cw,
+                                                const double* __restrict__ lvals,
+                                                const double* __restrict__ cw,
                                                 const double* __restrict__ wh,
                                                 double* __restrict__ bvals) {
   int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
+  const double ci = cw[i];
   for (int j = indptr[i]; j < indptr[i + 1]; ++j)
-    bvals[j] = cw * lvals[j] + (indices[j] == i ? wh[i] : 0.0);
+    bvals[j] = ci * lvals[j] + (indices[j] == i ? wh[i] : 0.0);
 }
 
 __device__ __forceinline__ bool strong(int i, int j, double v, const double* __restrict__ diag) {
@@ -697,7 +700,7 @@ static int aggregate(Ctx* c, AmgLevel& F, int32_t* d_counter, int* nc_out) {
   return 0;
 }
 
-int amg_build(Ctx* c, const DevCsr& Lm, int n, double cw, const double* wh, AmgHierarchy** out) {
+int amg_build(Ctx* c, const DevCsr& Lm, int n, const double* cw, const double* wh, AmgHierarchy** out) {
   *out = nullptr;
   AmgHierarchy* H = new AmgHierarchy();
   auto bail = [&](int rc) {

@@ -98,7 +98,7 @@ struct Scal {
   double rz[2][3], pq[2][3], rr[2][3], bb[3];
 };
 
-enum Op { OP_A = 0, OP_B = 1 };  // A = wl L L wl + wh^2 ; B = c L + wh
+enum Op { OP_A = 0, OP_B = 1 };  // A = wl L L wl + wh^2 ; B = wl L + wh (wl constant along the edges of L)
 
 // r = b - q (q = Op(x0), or absent when x0 = 0); z = Minv r; dir = z; rz, rr, bb.
 __global__ __launch_bounds__(256) void k_init(int n, const double* __restrict__ q /*may be null*/,
@@ -131,14 +131,14 @@ __global__ __launch_bounds__(256) void k_init(int n, const double* __restrict__ 
 
 // Sparse pass fused with the operator tail: t = L v for row i, then
 //   OP_A: q_i = wl_i * t + wh_i^2 * v_i    (v here is L(wl .* dir), `dirv` the CG direction)
-//   OP_B: q_i = c * t + wh_i * v_i
+//   OP_B: q_i = wl_i * t + wh_i * v_i
 // and pq += dirv_i * q_i. Saves one launch and one 3-column stream per iteration.
 template <int OP>
 __global__ __launch_bounds__(256) void k_spmv3_tail(int n, const int32_t* __restrict__ indptr,
                                                     const int32_t* __restrict__ indices,
                                                     const double* __restrict__ vals,
                                                     const double* __restrict__ x /*gathered*/,
-                                                    const double* __restrict__ wl, double c,
+                                                    const double* __restrict__ wl,
                                                     const double* __restrict__ wh,
                                                     const double* __restrict__ dirv,
                                                     double* __restrict__ q, Scal* __restrict__ sc,
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void k_spmv3_tail(int n, const int32_t* __rest
         a2 += v[u] * x2[u];
       }
     }
-    const double a = OP == OP_A ? wl[i] : c;
+    const double a = wl[i];
     const double h = OP == OP_A ? wh[i] * wh[i] : wh[i];
     const double t[3] = {a0, a1, a2};
 #pragma unroll
@@ -232,10 +232,11 @@ __global__ __launch_bounds__(256) void k_direction(int n, const double* __restri
   }
 }
 
-// 1 / diag(B),  B = c L + wh
+// 1 / diag(B),  B = wl L + wh
 __global__ __launch_bounds__(256) void k_diag_b(int n, const int32_t* __restrict__ indptr,
                                                 const int32_t* __restrict__ indices,
-                                                const double* __restrict__ vals, double c,
+                                                const double* __restrict__ vals,
+                                                const double* __restrict__ wl,
                                                 const double* __restrict__ wh,
                                                 double* __restrict__ minv) {
   int i = blockIdx.x * 256 + threadIdx.x;
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(256) void k_diag_b(int n, const int32_t* __restrict
   double lii = 0.0;
   for (int j = indptr[i]; j < indptr[i + 1]; ++j)
     if (indices[j] == i) lii += vals[j];
-  const double d = c * lii + wh[i];
+  const double d = wl[i] * lii + wh[i];
   minv[i] = d > 0.0 ? 1.0 / d : 1.0;
 }
 
@@ -339,8 +340,7 @@ struct System {
   DevCsr L;
   int n;
   Op op;
-  const double* wl;  // OP_A: per-point Laplacian weights
-  double c;          // OP_B: the (uniform) Laplacian weight
+  const double* wl;  // per-point Laplacian weights (OP_B: constant along every edge of L)
   const double* wh;
   const double* minv;
 };
@@ -370,10 +370,10 @@ static void apply_op(Ctx* c, const System& S, const Work& w, const double* v, do
     hipLaunchKernelGGL(k_spmv3, grid, block, 0, c->stream, S.n, S.L.indptr, S.L.indices, S.L.vals,
                        S.wl, v, w.t1);
     hipLaunchKernelGGL(k_spmv3_tail<OP_A>, grid, block, 0, c->stream, S.n, S.L.indptr, S.L.indices,
-                       S.L.vals, w.t1, S.wl, 0.0, S.wh, v, q, sc, par);
+                       S.L.vals, w.t1, S.wl, S.wh, v, q, sc, par);
   } else {
     hipLaunchKernelGGL(k_spmv3_tail<OP_B>, grid, block, 0, c->stream, S.n, S.L.indptr, S.L.indices,
-                       S.L.vals, v, static_cast<const double*>(nullptr), S.c, S.wh, v, q, sc, par);
+                       S.L.vals, v, S.wl, S.wh, v, q, sc, par);
   }
 }
 
@@ -568,7 +568,7 @@ static int amg_pcg(Ctx* c, const System& S, const Work& w, AmgHierarchy* H, cons
   *iters = 0;
   auto iteration = [&](int par) -> int {
     hipLaunchKernelGGL(k_spmv3_tail<OP_B>, grid, block, 0, c->stream, N, S.L.indptr, S.L.indices,
-                       S.L.vals, w.dir, static_cast<const double*>(nullptr), S.c, S.wh, w.dir, w.q,
+                       S.L.vals, w.dir, S.wl, S.wh, w.dir, w.q,
                        w.sc, par);
     hipLaunchKernelGGL(k_update_r, grid, block, 0, c->stream, N, w.dir, w.q, y, w.r, w.sc, par);
     PQ_TRY(amg_vcycle(c, H, w.r, w.z, w.sc->rz[par ^ 1]));
@@ -863,7 +863,7 @@ static int amg_pcg_f32(Ctx* c, int N, const WorkF& w, AmgHierarchy* H, const flo
 // steps and each step two Jacobi-PCG solves with B. cond(A) reaches 1e13 on
 // contracted clouds: far beyond what Jacobi-PCG on A itself can do.
 // Non-uniform wl: plain Jacobi-PCG on A.
-static int lbc_solve_core(Ctx* c, const DevCsr& L, int64_t n, const double* wl, double wl_uniform,
+static int lbc_solve_core(Ctx* c, const DevCsr& L, int64_t n, const double* wl, bool wl_edge_const,
                           const double* wh, const double* pts, double rtol, int32_t max_it, double* x,
                           int32_t* iters, double resid[3]) {
   const int N = int(n);
@@ -876,8 +876,8 @@ static int lbc_solve_core(Ctx* c, const DevCsr& L, int64_t n, const double* wl, 
   PQ_HIP(hipMemcpyAsync(x, pts, size_t(n) * 24, hipMemcpyDeviceToDevice, c->stream));
   Work wa;
   PQ_TRY(alloc_work(c, n, &wa));
-  System SA{L, N, OP_A, wl, 0.0, wh, minv_a};
-  if (!(wl_uniform > 0.0)) {
+  System SA{L, N, OP_A, wl, wh, minv_a};
+  if (!wl_edge_const) {
     hipLaunchKernelGGL(k_diag, grid, block, 0, c->stream, N, L.indptr, L.vals, wl, wh, minv_a);
     GraphCache cache;
     return jacobi_pcg(c, SA, wa, b, x, false, rtol, max_it, "lbc_cg_iter", &cache, iters, resid);
@@ -895,8 +895,8 @@ static int lbc_solve_core(Ctx* c, const DevCsr& L, int64_t n, const double* wl, 
   Work wb;
   PQ_TRY(alloc_work(c, n, &wb));
   hipLaunchKernelGGL(k_diag_b, grid, block, 0, c->stream, N, L.indptr, L.indices, L.vals,
-                     wl_uniform, wh, minv_b);
-  System SB{L, N, OP_B, nullptr, wl_uniform, wh, minv_b};
+                     wl, wh, minv_b);
+  System SB{L, N, OP_B, wl, wh, minv_b};
   // Multilevel preconditioner for the B-solves (amg.hip): 12-17 cycles per solve where
   // Jacobi-PCG needs 200-700 sparse passes. PYQSM_AMG=0 selects Jacobi-PCG; it is also
   // the fallback when no hierarchy can be built (tiny or fully decoupled systems).
@@ -904,7 +904,7 @@ static int lbc_solve_core(Ctx* c, const DevCsr& L, int64_t n, const double* wl, 
   const char* amg_env = getenv("PYQSM_AMG");
   if (!(amg_env && amg_env[0] == '0')) {
     ProfScope ps(c, "lbc_amg_build");
-    if (amg_build(c, L, N, wl_uniform, wh, &amg) != 0 || amg_levels(amg) < 2) {
+    if (amg_build(c, L, N, wl, wh, &amg) != 0 || amg_levels(amg) < 2) {
       amg_destroy(amg);
       amg = nullptr;
     }
@@ -1069,6 +1069,20 @@ static int lbc_solve_core(Ctx* c, const DevCsr& L, int64_t n, const double* wl, 
   return 0;
 }
 
+// flag = 1 when the Laplacian weight differs across some edge of L (then B = W_L L + W_H would
+// not be symmetric and the solve takes the plain path)
+__global__ __launch_bounds__(256) void k_edge_const(int n, const int32_t* __restrict__ indptr,
+                                                    const int32_t* __restrict__ indices,
+                                                    const double* __restrict__ wl,
+                                                    int32_t* __restrict__ flag) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const double w = wl[i];
+  bool differs = false;
+  for (int j = indptr[i]; j < indptr[i + 1]; ++j) differs |= wl[indices[j]] != w;
+  if (differs) *flag = 1;  // racing stores of the same value
+}
+
 // ---- spatially sorted unknowns -----------------------------------------------------------
 // Every sparse pass gathers 24-byte rows of a vector at the columns of a matrix row, i.e. at
 // the point's mesh neighbours. In the caller's point order those are anywhere in the
@@ -1098,8 +1112,10 @@ __global__ __launch_bounds__(256) void k_perm_fill(int n, const int32_t* __restr
                                                    int32_t* __restrict__ new_indices,
                                                    double* __restrict__ new_vals,
                                                    const double* __restrict__ wh,
+                                                   const double* __restrict__ wl,
                                                    const double* __restrict__ pts,
                                                    double* __restrict__ wh_p,
+                                                   double* __restrict__ wl_p,
                                                    double* __restrict__ pts_p) {
   int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
@@ -1110,6 +1126,7 @@ __global__ __launch_bounds__(256) void k_perm_fill(int n, const int32_t* __restr
     new_vals[w] = vals[j];
   }
   wh_p[i] = wh[o];
+  wl_p[i] = wl[o];
   pts_p[3 * i] = pts[3 * o];
   pts_p[3 * i + 1] = pts[3 * o + 1];
   pts_p[3 * i + 2] = pts[3 * o + 2];
@@ -1126,12 +1143,12 @@ __global__ __launch_bounds__(256) void k_perm_back(int n, const int32_t* __restr
   x[3 * o + 2] = x_p[3 * i + 2];
 }
 
-int lbc_solve_device(Ctx* c, const DevCsr& L, int64_t n, const double* wl, double wl_uniform,
+int lbc_solve_device(Ctx* c, const DevCsr& L, int64_t n, const double* wl, bool wl_edge_const,
                      const double* wh, const double* pts, double rtol, int32_t max_it, double* x,
                      int32_t* iters, double resid[3]) {
   const char* pe = getenv("PYQSM_LBC_SORT");
-  if (!(wl_uniform > 0.0) || n < 4096 || (pe && pe[0] == '0'))
-    return lbc_solve_core(c, L, n, wl, wl_uniform, wh, pts, rtol, max_it, x, iters, resid);
+  if (!wl_edge_const || n < 4096 || (pe && pe[0] == '0'))
+    return lbc_solve_core(c, L, n, wl, wl_edge_const, wh, pts, rtol, max_it, x, iters, resid);
   const int N = int(n);
   const dim3 grid(ceil_div(n, 256)), grid1(ceil_div(n + 1, 256)), block(256);
   // cells of ~1/512 of the extent (the dense grid is capped at 2^24 cells; the edge doubles to
@@ -1142,7 +1159,7 @@ int lbc_solve_device(Ctx* c, const DevCsr& L, int64_t n, const double* wl, doubl
   PQ_TRY(cloud_bbox(c, pts, n, mn, mx));
   double ext = std::max(mx[0] - mn[0], std::max(mx[1] - mn[1], mx[2] - mn[2]));
   if (!(ext > 0.0) || !std::isfinite(ext))
-    return lbc_solve_core(c, L, n, wl, wl_uniform, wh, pts, rtol, max_it, x, iters, resid);
+    return lbc_solve_core(c, L, n, wl, wl_edge_const, wh, pts, rtol, max_it, x, iters, resid);
   double box[6] = {mn[0], mn[1], mn[2], mx[0], mx[1], mx[2]};
   DevGrid g;
   PQ_TRY(build_grid(c, pts, n, ext / 512.0, int64_t(1) << 24, &g, box));
@@ -1151,22 +1168,22 @@ int lbc_solve_device(Ctx* c, const DevCsr& L, int64_t n, const double* wl, doubl
   PQ_HIP(hipStreamSynchronize(c->stream));
   int32_t* pos_of;
   DevCsr Lp;
-  double *wh_p, *pts_p, *x_p;
+  double *wh_p, *wl_p, *pts_p, *x_p;
   PQ_TRY(c->arena.get(size_t(n), &pos_of));
   PQ_TRY(c->arena.get(size_t(n) + 1, &Lp.indptr));
   PQ_TRY(c->arena.get(size_t(nnz) + 1, &Lp.indices));
   PQ_TRY(c->arena.get(size_t(nnz) + 1, &Lp.vals));
   PQ_TRY(c->arena.get(size_t(n), &wh_p));
+  PQ_TRY(c->arena.get(size_t(n), &wl_p));
   PQ_TRY(c->arena.get(size_t(n) * 3, &pts_p));
   PQ_TRY(c->arena.get(size_t(n) * 3, &x_p));
   hipLaunchKernelGGL(k_perm_invert, grid, block, 0, c->stream, N, g.order, pos_of);
   hipLaunchKernelGGL(k_perm_rowlen, grid1, block, 0, c->stream, N, g.order, L.indptr, Lp.indptr);
   PQ_TRY(exclusive_scan_i32(c, Lp.indptr, n + 1));
   hipLaunchKernelGGL(k_perm_fill, grid, block, 0, c->stream, N, g.order, pos_of, L.indptr, L.indices,
-                     L.vals, Lp.indptr, Lp.indices, Lp.vals, wh, pts, wh_p, pts_p);
+                     L.vals, Lp.indptr, Lp.indices, Lp.vals, wh, wl, pts, wh_p, wl_p, pts_p);
   PQ_HIP(hipGetLastError());
-  // wl is only read as "uniform" on this path (its entries are all wl_uniform)
-  const int rc = lbc_solve_core(c, Lp, n, wl, wl_uniform, wh_p, pts_p, rtol, max_it, x_p, iters, resid);
+  const int rc = lbc_solve_core(c, Lp, n, wl_p, wl_edge_const, wh_p, pts_p, rtol, max_it, x_p, iters, resid);
   if (rc != 0 && rc != PYQSM_ENOCONV) return rc;
   hipLaunchKernelGGL(k_perm_back, grid, block, 0, c->stream, N, g.order, x_p, x);
   PQ_HIP(hipGetLastError());
@@ -1215,13 +1232,14 @@ int pyqsm_lbc_solve(const int32_t* indptr, const int32_t* indices, const double*
   if (!indptr || !wl || !wh || !pts || !out)
     return fail(PYQSM_EINVAL, "pyqsm_lbc_solve: NULL pointer");
   if (!(rtol > 0)) return fail(PYQSM_EINVAL, "rtol must be positive");
-  // extract_skeleton always passes a uniform Laplacian weight (skeletonize.py:265,329,334)
-  double wl_uniform = wl[0];
-  for (int64_t i = 1; i < n; ++i)
-    if (wl[i] != wl[0]) {
-      wl_uniform = 0.0;
-      break;
-    }
+  // extract_skeleton always passes a uniform Laplacian weight (skeletonize.py:265,329,334);
+  // the fast path only needs it constant along every edge of L (checked on the device below):
+  // several clouds stacked into one block-diagonal system may each bring their own
+  bool wl_uniform = true, wl_positive = true;
+  for (int64_t i = 0; i < n; ++i) {
+    if (wl[i] != wl[0]) wl_uniform = false;
+    if (!(wl[i] > 0.0) || !std::isfinite(wl[i])) wl_positive = false;
+  }
   for (int64_t i = 0; i < n; ++i)
     if (!(wh[i] > 0.0) || !std::isfinite(wh[i]))
       return fail(PYQSM_EINVAL, "positional weights must be positive and finite");
@@ -1242,7 +1260,19 @@ int pyqsm_lbc_solve(const int32_t* indptr, const int32_t* indices, const double*
   PQ_HIP(hipMemcpyAsync(d_pts, pts, size_t(n) * 24, hipMemcpyHostToDevice, c->stream));
   int32_t it = 0;
   double rs[3] = {0, 0, 0};
-  int rc = lbc_solve_device(c, L, n, d_wl, wl_uniform, d_wh, d_pts, rtol, max_it, d_x, &it, rs);
+  bool wl_edge_const = wl_positive;
+  if (wl_positive && !wl_uniform) {
+    int32_t* d_flag;
+    PQ_TRY(c->arena.get(1, &d_flag));
+    PQ_HIP(hipMemsetAsync(d_flag, 0, 4, c->stream));
+    hipLaunchKernelGGL(k_edge_const, dim3(ceil_div(n, 256)), dim3(256), 0, c->stream, int(n), L.indptr,
+                       L.indices, d_wl, d_flag);
+    int32_t h_flag = 0;
+    PQ_HIP(hipMemcpyAsync(&h_flag, d_flag, 4, hipMemcpyDeviceToHost, c->stream));
+    PQ_HIP(hipStreamSynchronize(c->stream));
+    wl_edge_const = h_flag == 0;
+  }
+  int rc = lbc_solve_device(c, L, n, d_wl, wl_edge_const, d_wh, d_pts, rtol, max_it, d_x, &it, rs);
   if (iters) *iters = it;
   if (resid) {
     resid[0] = rs[0];

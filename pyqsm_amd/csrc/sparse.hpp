@@ -36,9 +36,10 @@ __device__ __forceinline__ void reduce3_atomic(double v0, double v1, double v2, 
 // Aggregation multigrid for B = c*L + diag(wh) (amg.hip). Opaque to callers.
 struct AmgHierarchy;
 
-// Builds the hierarchy for B = cw*L + diag(wh) of the n-point system. All device
+// Builds the hierarchy for B = diag(cw)*L + diag(wh) of the n-point system (cw [n], constant
+// along every edge of L). All device
 // memory comes from the context arena (valid until the next arena reset).
-int amg_build(Ctx* c, const DevCsr& L, int n, double cw, const double* wh, AmgHierarchy** out);
+int amg_build(Ctx* c, const DevCsr& L, int n, const double* cw, const double* wh, AmgHierarchy** out);
 void amg_destroy(AmgHierarchy* h);
 int amg_levels(const AmgHierarchy* h);
 
