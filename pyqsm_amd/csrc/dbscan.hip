@@ -243,9 +243,23 @@ __device__ __forceinline__ void unite(int* parent, int a, int b) {
   }
 }
 
-__global__ __launch_bounds__(256) void k_init_parent(int n, int* __restrict__ parent) {
+// Start of the union phase in one launch (it used to be a kernel and three memsets, ~4 us each):
+// every point its own parent, no smallest index yet, no cluster flags, empty lists.
+__global__ __launch_bounds__(256) void k_union_init(int n, int* __restrict__ parent,
+                                                    int* __restrict__ min_orig,
+                                                    int32_t* __restrict__ flag /*[n + 1]*/,
+                                                    int32_t* __restrict__ list_cnt /*[0], [2]*/) {
   int p = blockIdx.x * 256 + threadIdx.x;
-  if (p < n) parent[p] = p;
+  if (p < n) {
+    parent[p] = p;
+    min_orig[p] = 0x7F7F7F7F;  // > any index
+    flag[p] = 0;
+  }
+  if (p == 0) {
+    flag[n] = 0;
+    list_cnt[0] = 0;
+    list_cnt[2] = 0;
+  }
 }
 
 // ---- union phase over octant sub-cells -------------------------------------------------
@@ -571,14 +585,19 @@ __global__ __launch_bounds__(256) void k_rep_min(const int4* __restrict__ list, 
   }
 }
 
-// parent[p] = root for every core point (point -> representative -> root)
+// parent[p] = root for every core point (point -> representative -> root). With `flag` given
+// (the components' smallest indices are final by then) the roots also mark their cluster's
+// slot, which spares k_mark_roots.
 __global__ __launch_bounds__(256) void k_flatten(int n, const uint8_t* __restrict__ core,
-                                                 int* __restrict__ parent) {
+                                                 int* __restrict__ parent,
+                                                 const int* __restrict__ min_orig /*may be null*/,
+                                                 int32_t* __restrict__ flag /*may be null*/) {
   int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= n || !core[p]) return;
   int r = p;
   for (int nx = parent[r]; nx != r; nx = parent[r]) r = nx;
   parent[p] = r;  // benign: r is still an ancestor for concurrent readers
+  if (flag && r == p) flag[min_orig[p]] = 1;
 }
 
 __global__ __launch_bounds__(256) void k_mark_roots(int n, const uint8_t* __restrict__ core,
@@ -718,11 +737,8 @@ static int dbscan_device(Ctx* c, const double* xyz, int64_t n, double eps, int32
   }
   {
     ProfScope ps(c, "dbscan_union");
-    hipLaunchKernelGGL(k_init_parent, grid, block, 0, c->stream, N, parent);
-    PQ_HIP(hipMemsetAsync(min_orig, 0x7F, size_t(n) * 4, c->stream));  // 0x7F7F7F7F > any index
-    PQ_HIP(hipMemsetAsync(flag, 0, (size_t(n) + 1) * 4, c->stream));
+    hipLaunchKernelGGL(k_union_init, grid, block, 0, c->stream, N, parent, min_orig, flag, list_cnt);
     if (fine) {
-      PQ_HIP(hipMemsetAsync(list_cnt, 0, 4, c->stream));
       hipLaunchKernelGGL(k_sub_rep, dim3(ceil_div(n, 1024)), dim3(1024), 0, c->stream, N, sub.sub_of, sub.sub_beg, sub.sub_cnt,
                          core, g.order, parent, g.cell_of, sub.rec, run_min, list, list_cnt);
       int32_t m = 0;
@@ -749,15 +765,15 @@ static int dbscan_device(Ctx* c, const double* xyz, int64_t n, double eps, int32
         hipLaunchKernelGGL(k_rep_min, gl, block, 0, c->stream, list, m, parent, run_min, min_orig);
       }
       PQ_HIP(hipGetLastError());
-      hipLaunchKernelGGL(k_flatten, grid, block, 0, c->stream, N, core, parent);
+      hipLaunchKernelGGL(k_flatten, grid, block, 0, c->stream, N, core, parent, min_orig, flag);
     } else {
       hipLaunchKernelGGL(k_union_points, grid, block, 0, c->stream, N, st, g.start, g.cell_of, g.sx, g.sy,
                          g.sz, r2, core, parent);
-      hipLaunchKernelGGL(k_flatten, grid, block, 0, c->stream, N, core, parent);
+      hipLaunchKernelGGL(k_flatten, grid, block, 0, c->stream, N, core, parent, static_cast<const int*>(nullptr),
+                         static_cast<int32_t*>(nullptr));
       hipLaunchKernelGGL(k_point_min, grid, block, 0, c->stream, N, core, parent, g.order, min_orig);
-      PQ_HIP(hipGetLastError());
+      hipLaunchKernelGGL(k_mark_roots, grid, block, 0, c->stream, N, core, parent, min_orig, flag);
     }
-    hipLaunchKernelGGL(k_mark_roots, grid, block, 0, c->stream, N, core, parent, min_orig, flag);
     PQ_HIP(hipGetLastError());
     PQ_TRY(exclusive_scan_i32(c, flag, n + 1));
   }
