@@ -416,13 +416,35 @@ __global__ __launch_bounds__(256) void k_pyr_counts(Pyr P, const int32_t* __rest
   int run = 0;
   if (cx >= 1 && cy >= 1 && cz >= 1 && cx <= P.cnx - 2 && cy <= P.cny - 2 && cz <= P.cnz - 2) {
     const int x0 = (cx - 1) * P.factor + 1, y0 = (cy - 1) * P.factor + 1, z0 = (cz - 1) * P.factor + 1;
-    for (int z = z0; z < z0 + P.factor && z <= P.fnz - 2; ++z)
-      for (int y = y0; y < y0 + P.factor && y <= P.fny - 2; ++y)
-        for (int x = x0; x < x0 + P.factor && x <= P.fnx - 2; ++x) {
-          const int f = (z * P.fny + y) * P.fnx + x;
-          foff[f] = run;
-          run += fstart[f + 1] - fstart[f];
+    if (P.factor == 4) {
+      // the usual factor: the five run starts of a row of four fine cells are fetched together,
+      // all sixteen rows' loads can be in flight at once (one cell at a time they were a chain of
+      // 64 load-add-store steps: 0.36 ms for the 50 M-cell grid of a million points)
+#pragma unroll
+      for (int dz = 0; dz < 4; ++dz)
+#pragma unroll
+        for (int dy = 0; dy < 4; ++dy) {
+          const int z = z0 + dz, y = y0 + dy;
+          if (z > P.fnz - 2 || y > P.fny - 2) continue;
+          const int f0 = (z * P.fny + y) * P.fnx + x0;
+          const int nxr = min(4, P.fnx - 1 - x0);  // fine cells of this row inside the grid (>= 1)
+          int s[5];
+#pragma unroll
+          for (int u = 0; u < 5; ++u) s[u] = fstart[f0 + min(u, nxr)];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (u < nxr) foff[f0 + u] = run + (s[u] - s[0]);
+          run += s[4] - s[0];  // s[4] = fstart[f0 + nxr]: the clamped index above
         }
+    } else {
+      for (int z = z0; z < z0 + P.factor && z <= P.fnz - 2; ++z)
+        for (int y = y0; y < y0 + P.factor && y <= P.fny - 2; ++y)
+          for (int x = x0; x < x0 + P.factor && x <= P.fnx - 2; ++x) {
+            const int f = (z * P.fny + y) * P.fnx + x;
+            foff[f] = run;
+            run += fstart[f + 1] - fstart[f];
+          }
+    }
   }
   ccount[C] = run;
 }
