@@ -60,6 +60,13 @@ struct AmgLevel {
   // instead of 36); the hierarchy itself is built in fp64
   float* valsf = nullptr;     // A.vals as float
   float* dinvf = nullptr;
+  int nnz = 0;
+  // per ENTRY j of a level that has a coarser one: a_ij / l1_j and the aggregate of column j,
+  // so that the pre-smoothing pass does not gather dinv[col] and the post-smoothing pass does
+  // not gather agg[col] (each gather is a potential L1 miss, and misses are what these passes
+  // cost); same products, same bits
+  float* valsdf = nullptr;
+  int32_t* aggcol = nullptr;
   float *r = nullptr, *xa = nullptr, *xb = nullptr, *b = nullptr;  // [n,3]; xb unused on level 0
 };
 
@@ -336,6 +343,22 @@ __global__ __launch_bounds__(256) void k_level_floats(int n, const int32_t* __re
   dinvf[i] = float(dinv[i]);
 }
 
+__global__ __launch_bounds__(256) void k_entry_cols(int n, const int32_t* __restrict__ indptr,
+                                                    const int32_t* __restrict__ indices,
+                                                    const float* __restrict__ valsf,
+                                                    const float* __restrict__ dinvf,
+                                                    const int32_t* __restrict__ agg,
+                                                    float* __restrict__ valsdf,
+                                                    int32_t* __restrict__ aggcol) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  for (int j = indptr[i]; j < indptr[i + 1]; ++j) {
+    const int col = indices[j];
+    valsdf[j] = valsf[j] * dinvf[col];
+    aggcol[j] = agg[col];
+  }
+}
+
 // The cycle's fp32 vectors hold one float4 (x, y, z, 0) per row: a neighbour's entry is ONE
 // 16-byte gather instead of three 4-byte ones. These kernels are bound by the number of
 // cache lines their gathers touch (the L1 takes a divergent access a line at a time), and
@@ -377,7 +400,7 @@ static constexpr int kRowUnroll = 8;
 //   x = Dinv b ;  r = b - A x
 __global__ __launch_bounds__(256) void k_down(int n, const int32_t* __restrict__ indptr,
                                               const int32_t* __restrict__ indices,
-                                              const float* __restrict__ vals,
+                                              const float* __restrict__ valsd /* a_ij / l1_j */,
                                               const float* __restrict__ dinv,
                                               const float* __restrict__ b, float* __restrict__ x,
                                               float* __restrict__ r) {
@@ -393,13 +416,10 @@ __global__ __launch_bounds__(256) void k_down(int n, const int32_t* __restrict__
     for (int u = 0; u < kRowUnroll; ++u) {  // past the row's end: the row itself, weight 0
       const bool ok = j + u < e;
       col[u] = ok ? indices[j + u] : i;
-      v[u] = ok ? vals[j + u] : 0.f;
+      v[u] = ok ? valsd[j + u] : 0.f;
     }
 #pragma unroll
-    for (int u = 0; u < kRowUnroll; ++u) {
-      v[u] *= dinv[col[u]];
-      bc[u] = ld4(b, col[u]);
-    }
+    for (int u = 0; u < kRowUnroll; ++u) bc[u] = ld4(b, col[u]);
 #pragma unroll
     for (int u = 0; u < kRowUnroll; ++u) {
       a0 += v[u] * bc[u].x;
@@ -449,6 +469,7 @@ __global__ __launch_bounds__(256) void k_up(int n, const int32_t* __restrict__ i
                                             const float* __restrict__ vals,
                                             const float* __restrict__ dinv,
                                             const int32_t* __restrict__ agg,
+                                            const int32_t* __restrict__ aggcol /* agg of every entry's column */,
                                             const float* __restrict__ xc,
                                             const float* __restrict__ b,
                                             const float* __restrict__ x, TO* __restrict__ out,
@@ -468,12 +489,10 @@ __global__ __launch_bounds__(256) void k_up(int n, const int32_t* __restrict__ i
         const bool ok = j + u < e;
         col[u] = ok ? indices[j + u] : i;
         v[u] = ok ? vals[j + u] : 0.f;
+        ac[u] = ok ? aggcol[j + u] : -1;
       }
 #pragma unroll
-      for (int u = 0; u < kRowUnroll; ++u) {
-        ac[u] = agg[col[u]];
-        xv[u] = ld4(x, col[u]);
-      }
+      for (int u = 0; u < kRowUnroll; ++u) xv[u] = ld4(x, col[u]);
 #pragma unroll
       for (int u = 0; u < kRowUnroll; ++u) c4[u] = ac[u] >= 0 ? ld4(xc, ac[u]) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -734,6 +753,7 @@ int amg_build(Ctx* c, const DevCsr& Lm, int n, const double* cw, const double* w
   hipLaunchKernelGGL(k_diag_l1, dim3(ceil_div(n, 256)), dim3(256), 0, c->stream, n, l0.A.indptr,
                      l0.A.indices, l0.A.vals, l0.diag, l0.dinv);
   AMG_TRY(alloc_vectors(c, l0, false, nnz0));
+  l0.nnz = nnz0;
   H->lv.push_back(l0);
   // ---- coarsen -------------------------------------------------------------------------
   int32_t* d_flag = nullptr;
@@ -779,10 +799,19 @@ int amg_build(Ctx* c, const DevCsr& Lm, int n, const double* cw, const double* w
                        C.dinv);
     AMG_HIP(hipGetLastError());
     AMG_TRY(alloc_vectors(c, C, true, h2[0]));
+    C.nnz = h2[0];
     H->lv.push_back(C);
   }
   AmgLevel& last = H->lv.back();
   last.agg = nullptr;
+  for (size_t l = 0; l + 1 < H->lv.size(); ++l) {  // per-entry columns' 1/l1 and aggregate
+    AmgLevel& L = H->lv[l];
+    AMG_TRY(c->arena.get(size_t(L.nnz) + 1, &L.valsdf));
+    AMG_TRY(c->arena.get(size_t(L.nnz) + 1, &L.aggcol));
+    hipLaunchKernelGGL(k_entry_cols, dim3(ceil_div(L.n, 256)), dim3(256), 0, c->stream, L.n, L.A.indptr,
+                       L.A.indices, L.valsf, L.dinvf, L.agg, L.valsdf, L.aggcol);
+  }
+  AMG_HIP(hipGetLastError());
   if (last.n <= kCoarseMax && H->lv.size() > 1) {
     H->nc = last.n;
     AMG_TRY(coarse_inverse(c, last, &H->dense_inv));
@@ -836,7 +865,7 @@ static int vcycle_impl(Ctx* c, AmgHierarchy* H, const TV* b, TV* x, double* dot)
       break;
     }
     AmgLevel& C = H->lv[size_t(l) + 1];
-    hipLaunchKernelGGL(k_down, g, blk, 0, c->stream, L.n, L.A.indptr, L.A.indices, L.valsf, L.dinvf, bl,
+    hipLaunchKernelGGL(k_down, g, blk, 0, c->stream, L.n, L.A.indptr, L.A.indices, L.valsdf, L.dinvf, bl,
                        L.xa, L.r);
     hipLaunchKernelGGL(k_restrict, dim3(ceil_div(C.n, 256)), blk, 0, c->stream, C.n, L.mptr, L.members,
                        L.r, C.b);
@@ -849,10 +878,10 @@ static int vcycle_impl(Ctx* c, AmgHierarchy* H, const TV* b, TV* x, double* dot)
     if (l == 0)
       hipLaunchKernelGGL((k_up<TV, TV>), dot ? dim3(std::min<int64_t>(ceil_div(L.n, 256), 1024)) : g, blk, 0,
                          c->stream, L.n, L.A.indptr, L.A.indices, L.valsf,
-                         L.dinvf, L.agg, C.xb, b0, L.xa, x, dot ? b : static_cast<const TV*>(nullptr), dot);
+                         L.dinvf, L.agg, L.aggcol, C.xb, b0, L.xa, x, dot ? b : static_cast<const TV*>(nullptr), dot);
     else
       hipLaunchKernelGGL((k_up<float, float>), g, blk, 0, c->stream, L.n, L.A.indptr, L.A.indices,
-                         L.valsf, L.dinvf, L.agg, C.xb, L.b, L.xa, L.xb, static_cast<const float*>(nullptr),
+                         L.valsf, L.dinvf, L.agg, L.aggcol, C.xb, L.b, L.xa, L.xb, static_cast<const float*>(nullptr),
                          static_cast<double*>(nullptr));
   }
   PQ_HIP(hipGetLastError());
