@@ -181,8 +181,9 @@ int pyqsm_ransac_count(const double* pts, int64_t n, const double* models, int64
 /* ---- Laplacian-contraction solve --------------------------------------- */
 /*
  * One contraction solve of pyQSM/geometry/skeletonize.py:148-180
- * (least_squares_sparse): minimise |W_L L x|^2 + |W_H (x - p)|^2 per coordinate,
- * i.e. (L' W_L^2 L + W_H^2) x = W_H^2 p, by a preconditioned conjugate
+ * (least_squares_sparse): the reference stacks A = [L W_L ; W_H] (:164, the weights
+ * scale the COLUMNS of L), so this minimises |L W_L x|^2 + |W_H (x - p)|^2 per
+ * coordinate, i.e. (W_L L' L W_L + W_H^2) x = W_H^2 p, by a preconditioned conjugate
  * gradient over 3 right-hand sides that never forms L'L.
  *   L as CSR (indptr i32 [n+1], indices i32 [nnz], vals f64 [nnz]);
  *   wl, wh, f64 [n]; pts f64 [n,3] (also the start vector); out f64 [n,3]

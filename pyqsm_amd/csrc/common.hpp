@@ -99,6 +99,19 @@ class ProfScope {
   hipEvent_t start_ = nullptr;
 };
 
+// roctx range around a C-ABI entry point (tracing): shows up in
+// `rocprofv3 --marker-trace`. librocprofiler-sdk-roctx is looked up once at run time;
+// without it (or without a tool attached) a range costs two indirect calls.
+class ApiRange {
+ public:
+  explicit ApiRange(const char* name);
+  ~ApiRange();
+
+ private:
+  bool on_;
+};
+#define PQ_API_RANGE(name) ::pyqsm::ApiRange api_range__(name)
+
 inline int ceil_div(int64_t a, int64_t b) { return static_cast<int>((a + b - 1) / b); }
 
 // Exclusive prefix sum of n int32 values, in place, on the stream (scan.hip).

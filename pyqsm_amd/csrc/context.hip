@@ -1,7 +1,36 @@
 // context.hip — library/device management half of the C-ABI (include/pyqsm_hip.h).
 #include "common.hpp"
 
+#include <dlfcn.h>
+
 namespace pyqsm {
+
+// ---- roctx ranges --------------------------------------------------------
+namespace {
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx() {
+    void* h = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return;
+    push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+    pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+    if (!push || !pop) push = nullptr, pop = nullptr;
+  }
+};
+const Roctx& roctx() {
+  static Roctx r;
+  return r;
+}
+}  // namespace
+
+ApiRange::ApiRange(const char* name) : on_(roctx().push != nullptr) {
+  if (on_) roctx().push(name);
+}
+ApiRange::~ApiRange() {
+  if (on_) roctx().pop();
+}
 
 static thread_local char g_err[1024] = "";
 
@@ -160,6 +189,8 @@ struct ThreadHeld {
 };
 static thread_local ThreadHeld t_held;
 
+static void drain_timers(Ctx* c);
+
 Ctx* ctx_for(int device) {
   std::lock_guard<std::mutex> lk(g_mu);
   if (t_held.generation != g_generation) {
@@ -189,6 +220,12 @@ Ctx* ctx_for(int device) {
   if (!pool.idle.empty()) {
     Ctx* c = pool.idle.back();
     pool.idle.pop_back();
+    {  // a recycled context must not report the previous thread's launches
+      std::lock_guard<std::mutex> lc(c->mu);
+      drain_timers(c);
+      c->timers.clear();
+      c->prof = false;
+    }
     t_held.ctx[device] = c;
     return c;
   }
@@ -264,11 +301,17 @@ int pyqsm_shutdown(void) {
   std::lock_guard<std::mutex> lk(g_mu);
   for (auto& kv : pools()) {
     for (Ctx* c : kv.second.all) {
-      (void)hipSetDevice(c->device);
-      (void)hipStreamSynchronize(c->stream);
-      drain_timers(c);
-      c->arena.destroy();
-      (void)hipStreamDestroy(c->stream);
+      {
+        // a call still in flight on another thread holds c->mu: wait for it to leave before
+        // the arena and the stream go away. Callers must not START calls concurrently with
+        // pyqsm_shutdown (their thread-local pointers are stale once it returns).
+        std::lock_guard<std::mutex> lc(c->mu);
+        (void)hipSetDevice(c->device);
+        (void)hipStreamSynchronize(c->stream);
+        drain_timers(c);
+        c->arena.destroy();
+        (void)hipStreamDestroy(c->stream);
+      }
       delete c;
     }
   }

@@ -805,6 +805,7 @@ extern "C" {
 int pyqsm_dbscan_dev(const double* xyz_dev, int64_t n, double eps, int32_t min_pts,
                      int64_t* labels_dev, uint8_t* is_core_dev, int64_t* n_clusters,
                      int32_t device) {
+  PQ_API_RANGE("pyqsm_dbscan_dev");
   if (n < 0) return fail(PYQSM_EINVAL, "negative size");
   if (n > 0 && (!xyz_dev || !labels_dev)) return fail(PYQSM_EINVAL, "pyqsm_dbscan_dev: NULL pointer");
   Ctx* c = ctx_for(device);
@@ -817,6 +818,7 @@ int pyqsm_dbscan_dev(const double* xyz_dev, int64_t n, double eps, int32_t min_p
 
 int pyqsm_dbscan(const double* xyz, int64_t n, double eps, int32_t min_pts, int64_t* labels,
                  uint8_t* is_core, int32_t device) {
+  PQ_API_RANGE("pyqsm_dbscan");
   if (n < 0) return fail(PYQSM_EINVAL, "negative size");
   if (n == 0) return 0;
   if (!xyz || !labels) return fail(PYQSM_EINVAL, "pyqsm_dbscan: NULL pointer");

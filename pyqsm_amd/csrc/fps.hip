@@ -112,6 +112,7 @@ extern "C" {
 
 int pyqsm_fps(const double* xyz, int64_t n, int64_t num_samples, int64_t start_index,
               int32_t* out_idx, int32_t device) {
+  PQ_API_RANGE("pyqsm_fps");
   if (n < 0 || num_samples < 0) return fail(PYQSM_EINVAL, "negative size");
   if (num_samples == 0) return 0;
   if (num_samples > n) return fail(PYQSM_EINVAL, "num_samples exceeds the number of points");

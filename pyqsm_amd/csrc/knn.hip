@@ -529,6 +529,7 @@ extern "C" {
 
 int pyqsm_knn_dev(const double* xyz_dev, int64_t n, int32_t k, int32_t exclude_self,
                   int32_t* idx_dev, double* d2_dev, int32_t device) {
+  PQ_API_RANGE("pyqsm_knn_dev");
   if (n < 0) return fail(PYQSM_EINVAL, "negative size");
   if (n > 0 && (!xyz_dev || !idx_dev || !d2_dev))
     return fail(PYQSM_EINVAL, "pyqsm_knn_dev: NULL pointer");
@@ -542,6 +543,7 @@ int pyqsm_knn_dev(const double* xyz_dev, int64_t n, int32_t k, int32_t exclude_s
 
 int pyqsm_knn(const double* xyz, int64_t n, int32_t k, int32_t exclude_self, int32_t* idx,
               double* d2, int32_t device) {
+  PQ_API_RANGE("pyqsm_knn");
   if (n < 0) return fail(PYQSM_EINVAL, "negative size");
   if (n == 0) return 0;
   if (!xyz || !idx || !d2) return fail(PYQSM_EINVAL, "pyqsm_knn: NULL pointer");

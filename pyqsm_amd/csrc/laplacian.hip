@@ -832,6 +832,7 @@ extern "C" {
 int pyqsm_pc_laplacian(const double* xyz, int64_t n, int32_t k, double moll, int64_t* nnz_out,
                        int32_t** indptr_out, int32_t** indices_out, double** vals_out,
                        double* mass, int32_t device) {
+  PQ_API_RANGE("pyqsm_pc_laplacian");
   if (n < 0) return fail(PYQSM_EINVAL, "negative size");
   if (!nnz_out || !indptr_out || !indices_out || !vals_out)
     return fail(PYQSM_EINVAL, "pyqsm_pc_laplacian: NULL out-parameter");

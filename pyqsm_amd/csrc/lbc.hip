@@ -377,12 +377,10 @@ static void apply_op(Ctx* c, const System& S, const Work& w, const double* v, do
   }
 }
 
-// Plain launches instead of graph replays when asked to (PYQSM_NO_GRAPH) or when rocprofv3's
-// tool library is loaded: this ROCm's profiler crashes inside hipGraphLaunch of the
-// multigrid iteration graphs (kernel timings are unaffected by the switch).
-static bool graphs_enabled() {
-  return !getenv("PYQSM_NO_GRAPH") && !getenv("ROCP_TOOL_LIBRARIES");
-}
+// Plain launches instead of graph replays when PYQSM_NO_GRAPH is set. The library no longer
+// looks at the profiler's environment: tools/profile_*.sh export PYQSM_NO_GRAPH=1 themselves
+// where a profile is meant to show plain launches, and say so next to the profile.
+static bool graphs_enabled() { return !getenv("PYQSM_NO_GRAPH"); }
 
 // The multigrid-CG bursts are plain launches unless PYQSM_AMG_GRAPH is set: their graphs hold
 // 30-150 kernel nodes, are instantiated anew for every B-solve pair and replayed ~5 times, and
@@ -1198,6 +1196,7 @@ extern "C" {
 
 int pyqsm_spmv3(const int32_t* indptr, const int32_t* indices, const double* vals, int64_t n,
                 const double* x, double* y, int32_t device) {
+  PQ_API_RANGE("pyqsm_spmv3");
   if (n < 0) return fail(PYQSM_EINVAL, "negative size");
   if (n == 0) return 0;
   if (!indptr || !x || !y) return fail(PYQSM_EINVAL, "pyqsm_spmv3: NULL pointer");
@@ -1226,6 +1225,7 @@ int pyqsm_spmv3(const int32_t* indptr, const int32_t* indices, const double* val
 int pyqsm_lbc_solve(const int32_t* indptr, const int32_t* indices, const double* vals, int64_t n,
                     const double* wl, const double* wh, const double* pts, double rtol,
                     int32_t max_it, double* out, int32_t* iters, double* resid, int32_t device) {
+  PQ_API_RANGE("pyqsm_lbc_solve");
   if (n < 0) return fail(PYQSM_EINVAL, "negative size");
   if (iters) *iters = 0;
   if (n == 0) return 0;
@@ -1286,6 +1286,7 @@ int pyqsm_lbc_solve(const int32_t* indptr, const int32_t* indices, const double*
 }
 
 int pyqsm_clamp(double* pts, int64_t n, const double lo[3], const double hi[3], int32_t device) {
+  PQ_API_RANGE("pyqsm_clamp");
   if (n < 0) return fail(PYQSM_EINVAL, "negative size");
   if (n == 0) return 0;
   if (!pts || !lo || !hi) return fail(PYQSM_EINVAL, "pyqsm_clamp: NULL pointer");

@@ -115,6 +115,7 @@ extern "C" {
 int pyqsm_point_mesh_distance(const float* verts, int64_t V, const int32_t* tris, int64_t T,
                               const float* qry, int64_t Q, float* dist, uint32_t* prim,
                               int32_t device) {
+  PQ_API_RANGE("pyqsm_point_mesh_distance");
   if (V < 0 || T < 0 || Q < 0) return fail(PYQSM_EINVAL, "negative size");
   if (Q == 0) return 0;
   if (!qry || !dist || !prim) return fail(PYQSM_EINVAL, "pyqsm_point_mesh_distance: NULL pointer");

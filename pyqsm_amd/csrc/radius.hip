@@ -280,6 +280,7 @@ extern "C" {
 
 int pyqsm_ball_query(const double* xyz, int64_t n, const double center[3], double radius,
                      int64_t* out_idx, int64_t* count, int32_t device) {
+  PQ_API_RANGE("pyqsm_ball_query");
   if (n < 0) return fail(PYQSM_EINVAL, "negative size");
   if (count) *count = 0;
   if (n == 0) return 0;
@@ -319,6 +320,7 @@ int pyqsm_ball_query(const double* xyz, int64_t n, const double center[3], doubl
 
 int pyqsm_radius_mark(const double* src, int64_t n, const double* qry, int64_t m, double radius,
                       int32_t k_cap, uint8_t* mark, int32_t* counts, int32_t device) {
+  PQ_API_RANGE("pyqsm_radius_mark");
   if (n < 0 || m < 0) return fail(PYQSM_EINVAL, "negative size");
   if (n > 0 && (!src || !mark)) return fail(PYQSM_EINVAL, "pyqsm_radius_mark: NULL pointer");
   if (m > 0 && (!qry || !counts)) return fail(PYQSM_EINVAL, "pyqsm_radius_mark: NULL pointer");
@@ -360,6 +362,7 @@ int pyqsm_radius_mark(const double* src, int64_t n, const double* qry, int64_t m
 
 int pyqsm_radius_knn(const double* src, int64_t n, const double* qry, int64_t m, double radius,
                      int32_t k, int64_t* idx, double* dist, int32_t device) {
+  PQ_API_RANGE("pyqsm_radius_knn");
   if (n < 0 || m < 0) return fail(PYQSM_EINVAL, "negative size");
   if (k <= 0 || k > kKnnCap) return fail(PYQSM_ERANGE, "k must be in [1, %d]", kKnnCap);
   if (m > 0 && (!qry || !idx || !dist)) return fail(PYQSM_EINVAL, "pyqsm_radius_knn: NULL pointer");
@@ -404,6 +407,7 @@ int pyqsm_radius_knn(const double* src, int64_t n, const double* qry, int64_t m,
 int pyqsm_radius_label(const double* src, int64_t n, const double* qry, int64_t m,
                        const int32_t* qry_label, double radius, int32_t k_cap, int32_t* label,
                        int32_t* counts, int32_t device) {
+  PQ_API_RANGE("pyqsm_radius_label");
   if (n < 0 || m < 0) return fail(PYQSM_EINVAL, "negative size");
   if (n > 0 && (!src || !label)) return fail(PYQSM_EINVAL, "pyqsm_radius_label: NULL pointer");
   if (m > 0 && (!qry || !qry_label || !counts))

@@ -192,6 +192,7 @@ extern "C" {
 
 int pyqsm_ransac_models(const double* pts, int64_t n, const int64_t* triples, int64_t H,
                         double* models, int32_t device) {
+  PQ_API_RANGE("pyqsm_ransac_models");
   PQ_TRY(check_args(pts, n, H, 0));
   if (H == 0) return 0;
   if (!triples || !models) return fail(PYQSM_EINVAL, "pyqsm_ransac_models: NULL pointer");
@@ -218,6 +219,7 @@ int pyqsm_ransac_models(const double* pts, int64_t n, const int64_t* triples, in
 
 int pyqsm_ransac_count(const double* pts, int64_t n, const double* models, int64_t H,
                        int32_t shape, double thresh, int32_t* counts, int32_t device) {
+  PQ_API_RANGE("pyqsm_ransac_count");
   PQ_TRY(check_args(pts, n, H, shape));
   if (H == 0) return 0;
   if (!models || !counts) return fail(PYQSM_EINVAL, "pyqsm_ransac_count: NULL pointer");
@@ -243,6 +245,7 @@ int pyqsm_ransac_count(const double* pts, int64_t n, const double* models, int64
 int pyqsm_ransac(const double* pts, int64_t n, const int64_t* triples, int64_t H, int32_t shape,
                  double thresh, double center[3], double axis[3], double* radius,
                  int64_t* inliers, int64_t* n_inliers, int64_t* best_out, int32_t device) {
+  PQ_API_RANGE("pyqsm_ransac");
   PQ_TRY(check_args(pts, n, H, shape));
   if (n_inliers) *n_inliers = 0;
   if (best_out) *best_out = -1;

@@ -1208,6 +1208,7 @@ extern "C" {
 
 int pyqsm_expand_tris_dev(const float* verts_dev, int64_t V, const int32_t* tris_dev, int64_t T,
                           float* tri12_dev, int32_t device) {
+  PQ_API_RANGE("pyqsm_expand_tris_dev");
   PQ_TRY(check_sizes(V, T, 0));
   if (T > 0 && (!verts_dev || !tris_dev || !tri12_dev))
     return fail(PYQSM_EINVAL, "pyqsm_expand_tris_dev: NULL pointer");
@@ -1220,6 +1221,7 @@ int pyqsm_expand_tris_dev(const float* verts_dev, int64_t V, const int32_t* tris
 
 int pyqsm_cast_rays_dev(const float* tri12_dev, int64_t T, const float* rays_dev, int64_t R,
                         float* t_hit_dev, uint32_t* prim_id_dev, float* uv_dev, int32_t device) {
+  PQ_API_RANGE("pyqsm_cast_rays_dev");
   PQ_TRY(check_sizes(0, T, R));
   if (R > 0 && (!rays_dev || !t_hit_dev || !prim_id_dev || (T > 0 && !tri12_dev)))
     return fail(PYQSM_EINVAL, "pyqsm_cast_rays_dev: NULL pointer");
@@ -1234,6 +1236,7 @@ int pyqsm_cast_rays_dev(const float* tri12_dev, int64_t T, const float* rays_dev
 int pyqsm_cast_rays(const float* verts, int64_t V, const int32_t* tris, int64_t T,
                     const float* rays, int64_t R, float* t_hit, uint32_t* prim_id, float* uv,
                     int32_t device) {
+  PQ_API_RANGE("pyqsm_cast_rays");
   PQ_TRY(check_sizes(V, T, R));
   if (R == 0) return 0;
   if (!rays || !t_hit || !prim_id || (T > 0 && (!verts || !tris)))
@@ -1271,6 +1274,7 @@ int pyqsm_list_intersections(const float* verts, int64_t V, const int32_t* tris,
                              const float* rays, int64_t R, int32_t* counts, uint32_t* ray_ids,
                              uint32_t* prim_ids, float* t, float* uv, int64_t hits_cap,
                              int64_t* n_hits, int32_t device) {
+  PQ_API_RANGE("pyqsm_list_intersections");
   PQ_TRY(check_sizes(V, T, R));
   if (n_hits) *n_hits = 0;
   if (R == 0) return 0;

@@ -74,6 +74,19 @@ class TriangleMesh:
         used, inv = np.unique(tris, return_inverse=True)
         return TriangleMesh(self.vertices[used], inv.reshape(-1, 3))
 
+    def select_by_index(self, vertex_idx) -> "TriangleMesh":
+        """Open3D's legacy ``TriangleMesh.select_by_index``: the listed VERTICES, and every
+        triangle whose three vertices are all among them (also triangles nobody asked for,
+        on meshes that share vertices) in their original order."""
+        vid = np.asarray(vertex_idx, dtype=np.int64).reshape(-1)
+        new_of = np.full(len(self.vertices), -1, dtype=np.int64)
+        first = np.unique(vid, return_index=True)[1]
+        vid = vid[np.sort(first)]                      # duplicates keep their first position
+        new_of[vid] = np.arange(len(vid))
+        tris = new_of[self.triangles] if len(self.triangles) else np.zeros((0, 3), dtype=np.int64)
+        keep = (tris >= 0).all(axis=1)
+        return TriangleMesh(self.vertices[vid], tris[keep])
+
 
 class Cylinder:
     """The primitive fit_shape_RANSAC returns (the reference builds an Open3D

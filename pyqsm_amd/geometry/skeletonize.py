@@ -60,8 +60,13 @@ def _is_symmetric(L) -> bool:
     return abs(d).max() <= 1e-12 * max(scale, 1e-300)
 
 
+class ContractionSolveError(RuntimeError):
+    """Raised by ``least_squares_sparse(strict=True)`` when the solve stopped short of ``rtol``."""
+
+
 def least_squares_sparse(pts, L, laplacian_weighting, positional_weighting, trunk_points=None,
-                         rtol: float = SOLVER_RTOL, max_it: int = SOLVER_MAX_IT, device: int = 0):
+                         rtol: float = SOLVER_RTOL, max_it: int = SOLVER_MAX_IT, device: int = 0,
+                         info: list | None = None, strict: bool = False):
     """skeletonize.py:148-180: minimise |W_L-weighted Laplacian|^2 + |W_H (x - pts)|^2
     for each coordinate; returns the new positions float64 [n,3].
 
@@ -69,12 +74,23 @@ def least_squares_sparse(pts, L, laplacian_weighting, positional_weighting, trun
     solves the same normal equations by preconditioned CG on the GPU. ``L`` must
     be symmetric (the point-cloud Laplacian is). ``trunk_points`` is accepted and
     unused, as in the reference. If every entry of the solution is NaN the input
-    points are returned (:177-179)."""
+    points are returned (:177-179).
+
+    ``info`` (a list) receives one record per call: ``{"iters", "resid" (true relative
+    residuals |r|/|b| per coordinate), "ok"}`` — ``ok`` False means the solve stopped on
+    stagnation or ``max_it`` with the best iterate (PYQSM_ENOCONV). ``strict=True`` raises
+    :class:`ContractionSolveError` instead of only logging it."""
     pts = as_points(pts)
     if not _is_symmetric(L):
         raise ValueError("least_squares_sparse: L must be symmetric")
     x, iters, resid, ok = hip.lbc_solve(L, laplacian_weighting, positional_weighting, pts,
                                         rtol=rtol, max_it=max_it, device=device)
+    if info is not None:
+        info.append({"iters": iters, "resid": [float(v) for v in resid], "ok": bool(ok)})
+    if not ok and strict:
+        raise ContractionSolveError(
+            f"contraction solve stopped after {iters} CG iterations before the error estimate "
+            f"reached {rtol:.1e} (relative residual {resid.max():.3e})")
     if not ok:
         # the best iterate is returned; near cond(A) * 1e-16 the residual cannot go lower
         log.warning(f"contraction solve stopped after {iters} CG iterations before the error "
@@ -139,15 +155,21 @@ def extract_skeleton(pcd, moll=_SK["moll"], n_neighbors=_SK["n_neighbors"],
                      max_contraction=_SK["max_contraction"],
                      max_attraction=_SK["max_attraction"],
                      step_wise_contraction_amplification=_SK["step_wise_contraction_amplification"],
-                     cmag_save_file="", min_contraction=0, laplacian=None, device: int = 0):
+                     cmag_save_file="", min_contraction=0, laplacian=None, device: int = 0,
+                     strict: bool = False):
     """skeletonize.py:226-373. Returns ``(contracted, total_point_shift,
     shift_by_step)``: the contracted cloud (a PointCloud with ``.points``), the
     accumulated shift float64 [n,3] and the list of per-iteration shifts.
 
     ``laplacian`` (optional) replaces the point-cloud Laplacian: a callable
     ``pts -> (L, M)``. The shift pickles of the reference (:311-317, :353-367) are
-    written only when ``cmag_save_file`` is non-empty."""
+    written only when ``cmag_save_file`` is non-empty.
+
+    The returned cloud carries ``solve_log``: one ``{"iters", "resid", "ok"}`` record per
+    contraction solve (see :func:`least_squares_sparse`); ``strict=True`` makes a solve that
+    misses ``SOLVER_RTOL`` raise instead of feeding its best iterate to the next step."""
     pts = as_points(pcd)
+    solve_log = []
     allowed_range = oriented_bounds(pts)                               # :240-241
     lo, hi = np.asarray(allowed_range[0]), np.asarray(allowed_range[1])
     if laplacian is None:
@@ -179,7 +201,8 @@ def extract_skeleton(pcd, moll=_SK["moll"], n_neighbors=_SK["n_neighbors"],
         log.info(f"{volume_ratio=}, {np.mean(laplacian_weights)=}, {np.mean(positional_weights)=}")
         pts_new = least_squares_sparse(pts=pts_current, L=L,
                                        laplacian_weighting=laplacian_weights,
-                                       positional_weighting=positional_weights, device=device)
+                                       positional_weighting=positional_weights, device=device,
+                                       info=solve_log, strict=strict)
         if (pts_new == pts_current).all():                             # :287-289
             log.info("No more contraction in last iter, ending run.")
             break
@@ -206,7 +229,9 @@ def extract_skeleton(pcd, moll=_SK["moll"], n_neighbors=_SK["n_neighbors"],
         if volume_ratio < termination_ratio:                           # :361-367
             _dump("_tpshift.pkl")
     log.info(f"Finished after {iteration} iterations")
-    return PointCloud(pts_current), total_point_shift, shift_by_step
+    contracted = PointCloud(pts_current)
+    contracted.solve_log = solve_log
+    return contracted, total_point_shift, shift_by_step
 
 
 skeletonize = extract_skeleton   # BASELINE.json north_star name
@@ -271,35 +296,47 @@ def extract_skeletal_graph(skeletal_points: np.ndarray, graph_k_n, device: int =
 
 
 def simplify_graph(G):
-    """skeletonize.py:57-98: remove every node of degree 2 and fuse its two edges; the
-    fused edge remembers the removed nodes in its ``data`` list. Returns
-    ``(graph, kept_node_positions, kept_node_indices)``."""
-    g = G.copy()
-    keept_node_pos = []
-    keept_node_idx = []
-    while any(degree == 2 for _, degree in g.degree):
-        keept_node_pos = []
-        keept_node_idx = []
-        g0 = g.copy()
-        for node, degree in g.degree():
-            if degree == 2:
-                edges = list(g0.edges(node, data=True))
-                a0, b0, data0 = edges[0]
-                a1, b1, data1 = edges[1]
-                e0 = a0 if a0 != node else b0
-                e1 = a1 if a1 != node else b1
-                edata = data0.get("data", []) + data1.get("data", [])
-                edata.append(node)
-                g0.remove_node(node)
-                g0.add_edge(e0, e1, data=edata)
-            else:
-                keept_node_pos.append(g.nodes[node]["pos"])
-                keept_node_idx.append(node)
-        g = g0
-    if not keept_node_idx:                      # nothing was simplified: keep every node
-        keept_node_idx = list(g.nodes)
-        keept_node_pos = [g.nodes[v]["pos"] for v in keept_node_idx]
-    return g, keept_node_pos, keept_node_idx
+    """What skeletonize.py:57-98 computes, as one chain-collapsing pass: every maximal run
+    of degree-2 nodes between two other nodes (junctions, leaves) becomes ONE edge whose
+    ``data`` list names the nodes of the run, in walking order from the end that comes first
+    in the graph's node order.
+    Returns ``(graph, kept_node_positions, kept_node_indices)`` with the kept nodes in the
+    graph's node order. A graph without degree-2 nodes is returned unchanged with every
+    node kept; rings that consist of degree-2 nodes only (no end to start a walk from,
+    impossible in the spanning tree extract_topology passes in) are left as they are."""
+    import networkx as nx
+    kept = [v for v, d in G.degree() if d != 2]
+    kept_set = set(kept)
+    out = nx.Graph()
+    out.add_nodes_from((v, G.nodes[v]) for v in kept)
+    walked = set()                                   # degree-2 nodes already assigned to an edge
+    for u in kept:
+        for first in G.neighbors(u):
+            if first in kept_set:                    # a direct edge between two kept nodes
+                if not out.has_edge(u, first):
+                    out.add_edge(u, first, **G.edges[u, first])
+                continue
+            if first in walked:
+                continue                             # this run was walked from its other end
+            run, prev, cur = [], u, first
+            while cur not in kept_set:
+                run.append(cur)
+                walked.add(cur)
+                a, b = G.neighbors(cur)
+                prev, cur = cur, (b if a == prev else a)
+            members = []
+            for (x, y) in zip([u] + run, run + [cur]):   # nodes fused into the original edges
+                members += G.edges[x, y].get("data", [])
+            members += run
+            if out.has_edge(u, cur):                 # two runs between the same pair of nodes
+                members = out.edges[u, cur].get("data", []) + members
+            out.add_edge(u, cur, data=members)
+    rings = [v for v in G.nodes if v not in kept_set and v not in walked]
+    if rings:
+        out.add_nodes_from((v, G.nodes[v]) for v in rings)
+        out.add_edges_from((x, y, d) for x, y, d in G.edges(rings, data=True))
+        kept = [v for v in G.nodes if v in kept_set or v in set(rings)]
+    return out, [G.nodes[v]["pos"] for v in kept], kept
 
 
 def simplify_and_update(graph):

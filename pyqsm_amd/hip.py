@@ -281,7 +281,8 @@ def _csr(L):
 
 
 def lbc_solve(L, wl, wh, pts, rtol: float = 1e-10, max_it: int = 20000, device: int = 0):
-    """Solve (L' W_L^2 L + W_H^2) x = W_H^2 p for the three coordinates.
+    """Solve (W_L L' L W_L + W_H^2) x = W_H^2 p (A = [L W_L ; W_H], skeletonize.py:164) for the
+    three coordinates.
     Returns (x [n,3], iterations, relative residuals [3])."""
     indptr, indices, data, n = _csr(L)
     p = _points(pts)

@@ -161,8 +161,11 @@ def cast_rays(tmesh, surf_2d: bool = False, img: bool = False, pinhole_config=pi
 
     Returns the ``cast_rays`` dict ('t_hit', 'primitive_ids', 'primitive_uvs') plus
     'hit' (bool mask) and 'rays'; with ``surf_2d`` also 'hit_triangles' (unique hit
-    triangle ids), 'hit_mesh', 'surface_area_3d' and 'surface_area_2d' (the hit
-    triangles flattened to z = 0), the quantities of :285-303. (The reference
+    triangle ids), 'hit_mesh', 'surface_area_3d' and 'surface_area_2d' (that mesh
+    flattened to z = 0), the quantities of :285-303. As in the reference (:286-292)
+    'hit_mesh' is selected BY VERTEX: ``select_by_index(unique vertices of the hit
+    triangles)`` keeps every triangle whose three vertices were all hit, which on a mesh
+    with shared vertices includes triangles no ray reached. (The reference
     returns an undefined name when ``surf_2d`` is false.) ``rays`` overrides the
     camera, e.g. with parallel sun rays. ``img`` is accepted and ignored."""
     verts, tris = mesh_arrays(tmesh)
@@ -181,8 +184,9 @@ def cast_rays(tmesh, surf_2d: bool = False, img: bool = False, pinhole_config=pi
     out = dict(ans, hit=hit, rays=np.asarray(rays))
     if surf_2d:
         log.info("getting surface area")
-        tri_ids = np.unique(ans["primitive_ids"][hit])                 # :286-290
-        hit_mesh = TriangleMesh(verts, tris).select_by_triangle(tri_ids)
+        tri_ids = np.unique(ans["primitive_ids"][hit])                 # :286-289
+        hit_vert_ids = np.unique(tris[tri_ids.astype(np.int64)])       # :290
+        hit_mesh = TriangleMesh(verts, tris).select_by_index(hit_vert_ids)   # :291
         flat = TriangleMesh(hit_mesh.vertices * np.float32([1, 1, 0]), hit_mesh.triangles)
         out.update(hit_triangles=tri_ids, hit_mesh=hit_mesh,
                    surface_area_3d=hit_mesh.get_surface_area(),       # :292

@@ -48,23 +48,23 @@ def test_tiny_and_empty(gpu):
 
 def test_extract_skeleton_end_to_end(gpu):
     """configs[2] in miniature: the full loop (HIP Laplacian + HIP solve + HIP clamp)
-    against the oracle loop (oracle Laplacian + SciPy spsolve).
-
-    Tolerance: 1e-5 relative (BASELINE.json) on the first contraction. From the
-    second contraction on the normal equations reach cond ~ 1e12-1e13 and SuperLU
-    itself is only reproducible to ~1.4e-5 when its column ordering is changed
-    (DESIGN.md "Contraction solve"), so the whole 3-step loop is held to 1e-4."""
+    against the oracle loop (oracle Laplacian + SciPy spsolve), every step and the totals
+    held to north_star's 1e-5 relative. (tests/test_gpu_config3.py pins the same bound per
+    solve at init_contraction 7 and measures SuperLU's own error beside it.)"""
     P = synth.forest(2500, seed=9)
-    got, total, steps = sk.extract_skeleton(P, max_iter=3, contraction_factor=3,
+    got, total, steps = sk.extract_skeleton(P, max_iter=5, contraction_factor=3,
                                             attraction_factor=3, termination_ratio=0.0)
     lo, hi = sk.oriented_bounds(P)
     want, want_total, want_steps = oracle.extract_skeleton(
-        P, lambda p: oracle.point_cloud_laplacian(p, 20, 1e-6), (lo, hi), max_iter=3,
+        P, lambda p: oracle.point_cloud_laplacian(p, 20, 1e-6), (lo, hi), max_iter=5,
         termination_ratio=0.0, contraction_factor=3, attraction_factor=3)
-    assert len(steps) == len(want_steps) == 3
+    assert len(steps) == len(want_steps) == 5
     scale = np.abs(want).max()
-    assert np.abs(steps[0] - want_steps[0]).max() <= 1e-5 * scale
-    assert np.abs(got.points - want).max() <= 1e-4 * scale
-    assert np.abs(total - want_total).max() <= 1e-4 * scale
+    errs = [np.abs(a - b).max() / scale for a, b in zip(steps, want_steps)]
+    print("per-step max rel diff", ["%.1e" % e for e in errs])
+    assert max(errs) <= 1e-5
+    assert np.abs(got.points - want).max() <= 1e-5 * scale
+    assert np.abs(total - want_total).max() <= 1e-5 * scale
+    assert all(s["ok"] for s in got.solve_log)
     # the cloud really contracted
     assert np.linalg.norm(total, axis=1).mean() > 0.01

@@ -204,3 +204,60 @@ def test_adopted_buffers_are_released_after_the_last_view():
     del view
     gc.collect()
     assert freed == [raw]
+
+
+def test_simplify_graph_collapses_every_degree_two_run():
+    """skeletonize.py:57-98: against a one-node-at-a-time elimination on random trees."""
+    import networkx as nx
+    from pyqsm_amd.geometry.skeletonize import simplify_graph, simplify_and_update
+    rng = np.random.default_rng(5)
+    for trial in range(20):
+        n = int(rng.integers(2, 120))
+        G = nx.Graph()
+        G.add_nodes_from(range(n))
+        for v in range(1, n):                        # random tree, long chains likely
+            G.add_edge(v, int(rng.integers(max(0, v - 3), v)))
+        for v in G.nodes:
+            G.nodes[v]["pos"] = rng.normal(size=3)
+        got, pos, idx = simplify_graph(G)
+        ref = G.copy()
+        for v in list(ref.nodes):
+            if ref.degree(v) == 2:
+                (a, da), (b, db) = [(w, ref.edges[v, w].get("data", [])) for w in ref.neighbors(v)]
+                ref.remove_node(v)
+                ref.add_edge(a, b, data=da + db + [v])
+        assert set(got.nodes) == set(ref.nodes) and not any(d == 2 for _, d in got.degree())
+        assert {frozenset(e) for e in got.edges} == {frozenset(e) for e in ref.edges}
+        for a, b, d in ref.edges(data=True):
+            assert sorted(got.edges[a, b].get("data", [])) == sorted(d.get("data", []))
+        assert idx == [v for v in G.nodes if G.degree(v) != 2]
+        assert all(np.array_equal(p, G.nodes[v]["pos"]) for p, v in zip(pos, idx))
+        removed = sum(len(d.get("data", [])) for _, _, d in got.edges(data=True))
+        assert removed == n - len(idx)
+        # the run is listed in walking order: consecutive members are neighbours in G
+        for a, b, d in got.edges(data=True):
+            run = d.get("data", [])
+            assert all(G.has_edge(x, y) for x, y in zip(run, run[1:]))
+        relabeled, pts, mapping = simplify_and_update(G)
+        assert sorted(relabeled.nodes) == list(range(len(idx))) and pts.shape == (len(idx), 3)
+
+
+def test_select_by_index_is_by_vertex_like_open3d():
+    """ray_casting.py:286-292 selects the hit mesh by VERTEX: on a grid plane (shared vertices)
+    triangles whose three vertices were all hit come along although no ray hit them."""
+    from pyqsm_amd.geometry.cloud import TriangleMesh
+    g = 4
+    v = np.array([[x, y, 0.0] for y in range(g) for x in range(g)], dtype=np.float32)
+    t = []
+    for y in range(g - 1):
+        for x in range(g - 1):
+            a = y * g + x
+            t += [[a, a + 1, a + g], [a + 1, a + g + 1, a + g]]
+    m = TriangleMesh(v, np.array(t))
+    hit = [0, 3]            # lower triangle of cell (0,0) and upper triangle of cell (1,0)
+    verts = np.unique(m.triangles[hit])
+    sel = m.select_by_index(verts)
+    # vertices {0,1,4} + {2,5,6}: triangle 1 = (1,5,4) and 2 = (1,2,5) are now complete as well
+    assert len(sel.triangles) == 4 and abs(sel.get_surface_area() - 2.0) < 1e-12
+    assert abs(m.select_by_triangle(hit).get_surface_area() - 1.0) < 1e-12
+    assert np.array_equal(sel.vertices, v[verts])
