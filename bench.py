@@ -12,8 +12,9 @@ shard: at N > 1 every rank clusters its own forest (replicas, weak scaling) and
 
 Secondary sections on the same JSON line:
   ray_sweep   500 k-triangle canopy x R sun rays, Mray-tri/s (= R*T/t); rays are
-              sharded over the ranks, the mesh is broadcast and the per-shard
-              results all-gathered with RCCL (strong scaling, R fixed)
+              sharded over the ranks, the expanded mesh is broadcast and the per-shard
+              results all-gathered by the library's own RCCL communicator (pyqsm_comm_*;
+              strong scaling, R fixed)
   knn         k = 20 neighbours on the same cloud
   roofline    dominant kernel of the primary path, HIP-event timed live
   skeleton    the first --skel-iters Laplacian contractions of extract_skeleton on the
@@ -75,31 +76,32 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
-    dist = torch = None
-    # PYQSM_BENCH_FORCE_DIST=1 exercises the RCCL code path with a single rank
-    if world > 1 or os.environ.get("PYQSM_BENCH_FORCE_DIST") == "1":
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
     from pyqsm_amd import _lib, hip, synth
-    from pyqsm_amd.parallel import shard_bounds, shard_sizes
+    from pyqsm_amd.parallel import NativeComm, ShardedSweep, shard_bounds
     dev = local_rank
     _lib.require_gpu(dev)
 
+    # N > 1: one process per GPU. Every byte of the data path (mesh broadcast, result
+    # all-gather) and the barrier / max-over-ranks of the timing go through the library's own
+    # RCCL communicator (pyqsm_comm_*, multi.hip). torch.distributed is used for ONE thing: the
+    # CPU (gloo) rendezvous that hands rank 0's 128-byte RCCL id to the other ranks.
+    # PYQSM_BENCH_FORCE_DIST=1 exercises the same path with a single rank.
+    comm = dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        dist.init_process_group("gloo")
+        comm = NativeComm.from_torch(dist, dev)
+    elif os.environ.get("PYQSM_BENCH_FORCE_DIST") == "1":
+        comm = NativeComm(NativeComm.new_id(), 1, 0, dev)
+
     def barrier():
-        hip.sync(dev)
-        if dist is not None:
-            torch.cuda.synchronize()
-            dist.barrier()
+        hip.sync(dev)                 # the library stream carries all of this process's GPU work
+        if comm is not None:
+            comm.barrier()
 
     def max_over_ranks(x: float) -> float:
-        if dist is None:
-            return x
-        t = torch.tensor([x], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
+        return x if comm is None else comm.max_over_ranks(x)
 
     # ------------------------------------------------------------- DBSCAN (primary)
     n = args.points
@@ -180,37 +182,22 @@ def main():
     # ------------------------------------------------------------- ray sweep
     if not args.no_rays:
         T, R = args.tris, args.rays
-        verts, tris = synth.canopy_mesh(T)           # same seed on every rank
-        if dist is not None:                         # the mesh travels over RCCL
-            tv = torch.from_numpy(verts).cuda() if rank == 0 else torch.empty(
-                verts.shape, dtype=torch.float32, device="cuda")
-            tt = torch.from_numpy(tris).cuda() if rank == 0 else torch.empty(
-                tris.shape, dtype=torch.int32, device="cuda")
-            dist.broadcast(tv, src=0)
-            dist.broadcast(tt, src=0)
-            verts, tris = tv.cpu().numpy(), tt.cpu().numpy()
-        mesh = hip.DeviceMesh(verts, tris, dev)
+        verts, tris = synth.canopy_mesh(T)           # same seed on every rank (rays need its bbox)
         b, e = shard_bounds(R, world, rank)
         rays = synth.sun_rays(verts, R)[b:e]
-        d_rays = hip.DeviceBuffer.from_array(rays, dev)
         r_loc = e - b
-        sizes = shard_sizes(R, world)
-        cap = max(sizes)
-        if dist is not None:
-            # results live in torch tensors so that RCCL can gather them in place
-            res = torch.zeros((2, cap), dtype=torch.int32, device="cuda")
-            gathered = [torch.empty_like(res) for _ in range(world)]
-            t_ptr, p_ptr = res[0].data_ptr(), res[1].data_ptr()
+        if comm is not None:
+            # rank 0 expands the mesh, the records travel over RCCL, results are all-gathered
+            sharded = ShardedSweep(comm, verts, tris, rays, R)
+            sweep = sharded.run
         else:
-            d_t = hip.DeviceBuffer(cap * 4, dev)
-            d_p = hip.DeviceBuffer(cap * 4, dev)
-            t_ptr, p_ptr = d_t.ptr, d_p.ptr
+            mesh = hip.DeviceMesh(verts, tris, dev)
+            d_rays = hip.DeviceBuffer.from_array(rays, dev)
+            d_t = hip.DeviceBuffer(r_loc * 4, dev)
+            d_p = hip.DeviceBuffer(r_loc * 4, dev)
 
-        def sweep():
-            hip.cast_rays_dev(mesh, d_rays.ptr, r_loc, t_ptr, p_ptr)
-            if dist is not None:
-                hip.sync(dev)
-                dist.all_gather(gathered, res)
+            def sweep():
+                hip.cast_rays_dev(mesh, d_rays.ptr, r_loc, d_t.ptr, d_p.ptr)
 
         def timed(steps, prof_name):
             sweep()                                   # warm-up
@@ -227,9 +214,8 @@ def main():
             return dt / steps, ms / max(cnt, 1)
 
         def hits():
-            if dist is not None:
-                return np.concatenate([gathered[r][0, : sizes[r]].cpu().numpy().view(np.float32)
-                                       for r in range(world)])
+            if comm is not None:
+                return sharded.results()[0]
             return d_t.download((r_loc,), np.float32)
 
         # (1) the brute-force sweep BASELINE.json's Mray-tri/s is defined on: every ray
@@ -384,6 +370,8 @@ def main():
 
     if rank == 0:
         print(json.dumps(out))
+    if comm is not None:
+        comm.close()
     if dist is not None:
         dist.destroy_process_group()
 

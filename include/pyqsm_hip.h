@@ -123,6 +123,42 @@ int pyqsm_point_mesh_distance(const float* verts, int64_t V, const int32_t* tris
                               const float* qry, int64_t Q, float* dist, uint32_t* prim,
                               int32_t device);
 
+/* ---- the ray sweep over several GPUs (RCCL over xGMI) ------------------ */
+/*
+ * One process driving n_devices GPUs of the node (stands in for
+ * scene.cast_rays(rays) at pyQSM/viz/ray_casting.py:275-279 on more than one GPU):
+ * the mesh is expanded on device 0 and replicated with ncclBroadcast, rays are split
+ * into contiguous shards (sizes differ by at most one, in device order), every device
+ * sweeps its shard, and ncclAllGather leaves the full (t, prim[, uv]) on every device;
+ * device 0's copy goes to the host arrays. Results are identical to pyqsm_cast_rays
+ * (rays are independent). Same argument meaning as pyqsm_cast_rays; n_devices <= 0
+ * means every visible GPU; n_devices = 1 still goes through RCCL.
+ */
+int pyqsm_cast_rays_multi(const float* verts, int64_t V, const int32_t* tris, int64_t T,
+                          const float* rays, int64_t R,
+                          float* t_hit, uint32_t* prim_id, float* uv, int32_t n_devices);
+
+/*
+ * One process PER GPU (torchrun-style launches): a communicator per process and the
+ * data-path collectives on the library stream of the rank's device. Rank 0 creates the
+ * id and ships its PYQSM_COMM_ID_BYTES bytes to the other ranks by any means (a file, a
+ * socket, a CPU rendezvous); pyqsm_comm_init_rank is collective. The _dev calls take
+ * device pointers and are asynchronous until pyqsm_sync(device).
+ *   broadcast: in place, `bytes` from rank `root`;  all_gather: recv holds world *
+ *   bytes_per_rank, rank r's block at offset r * bytes_per_rank (send may alias its
+ *   own block);  all_reduce_max: host scalar in/out, returns when every rank has the
+ *   maximum (doubles as a barrier).
+ */
+#define PYQSM_COMM_ID_BYTES 128
+int pyqsm_comm_unique_id(uint8_t* id);
+int pyqsm_comm_init_rank(const uint8_t* id, int32_t world, int32_t rank, int32_t device);
+int pyqsm_comm_finalize(void);
+/* world = 0 when no communicator exists */
+int pyqsm_comm_info(int32_t* world, int32_t* rank, int32_t* device);
+int pyqsm_comm_broadcast_dev(void* buf_dev, int64_t bytes, int32_t root);
+int pyqsm_comm_all_gather_dev(const void* send_dev, void* recv_dev, int64_t bytes_per_rank);
+int pyqsm_comm_all_reduce_max(double* value);
+
 /* ---- eps-neighbourhood clustering (DBSCAN) ---------------------------- */
 /*
  * Stands in for sklearn.cluster.DBSCAN(eps, min_samples).fit(points) at

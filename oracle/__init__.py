@@ -30,8 +30,8 @@ _LIB = None
 def build(force: bool = False) -> str:
     """Compile liboracle.so with gcc (no-op when it is up to date)."""
     so = os.path.join(_HERE, "liboracle.so")
-    src = os.path.join(_HERE, "pyqsm_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("pyqsm_oracle.c", "ray_f64.c")]
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(map(os.path.getmtime, srcs)):
         subprocess.run(["make", "-C", _HERE, "-B", "liboracle.so"], check=True,
                        stdout=subprocess.DEVNULL)
     return so
@@ -58,6 +58,10 @@ def _lib():
         lib.orc_free.restype = None
         lib.orc_point_mesh_distance.argtypes = [p, i64, p, i64, p, i64, p, p]
         lib.orc_free.argtypes = [p]
+        lib.orc_cast_rays_f64.restype = ctypes.c_int
+        lib.orc_cast_rays_f64.argtypes = [p, p, i64, p, i64, p, p, p, p]
+        lib.orc_ray_tri_pairs_f64.restype = ctypes.c_int
+        lib.orc_ray_tri_pairs_f64.argtypes = [p, p, p, i64, p, p, p, p]
         _LIB = lib
     return _LIB
 
@@ -137,6 +141,40 @@ def cast_rays(verts, tris, rays):
         raise MemoryError("orc_cast_rays")
     return t_hit, prim, uv
 
+
+
+def cast_rays_f64(verts, tris, rays):
+    """INDEPENDENT closest hit (oracle/ray_f64.c: double precision, signed-volume formulation —
+    not the operation order of the HIP kernels or of :func:`cast_rays`).
+    Returns t f64 [R] (+inf miss), prim i64 [R] (-1 miss), bary f64 [R,3] (weights of v0, v1,
+    v2; u = bary[:,1], v = bary[:,2] in ray_casting.py:172-180's convention) and the depth of
+    the runner-up hit f64 [R] (+inf if none)."""
+    v = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 3)
+    t = np.ascontiguousarray(tris, dtype=np.int32).reshape(-1, 3)
+    r = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)
+    R = r.shape[0]
+    t_hit, second = np.empty(R), np.empty(R)
+    prim = np.empty(R, dtype=np.int64)
+    bary = np.empty((R, 3))
+    _lib().orc_cast_rays_f64(_ptr(v), _ptr(t), t.shape[0], _ptr(r), R, _ptr(t_hit), _ptr(prim),
+                             _ptr(bary), _ptr(second))
+    return t_hit, prim, bary, second
+
+
+def ray_tri_pairs_f64(verts, tris, rays, prim):
+    """What double precision says about GIVEN (ray, triangle) pairs: (pierces bool [R], t f64 [R],
+    bary f64 [R,3]); rows with prim < 0 are skipped (False / NaN)."""
+    v = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 3)
+    t = np.ascontiguousarray(tris, dtype=np.int32).reshape(-1, 3)
+    r = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)
+    pr = np.ascontiguousarray(prim, dtype=np.int64).reshape(-1)
+    R = r.shape[0]
+    pierces = np.zeros(R, dtype=np.uint8)
+    tt = np.empty(R)
+    bary = np.empty((R, 3))
+    _lib().orc_ray_tri_pairs_f64(_ptr(v), _ptr(t), _ptr(r), R, _ptr(pr), _ptr(pierces), _ptr(tt),
+                                 _ptr(bary))
+    return pierces.astype(bool), tt, bary
 
 
 def interception_layers(verts, tris, rays, max_rounds=None):

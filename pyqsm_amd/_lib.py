@@ -38,6 +38,15 @@ SIGNATURES = {
     "pyqsm_list_intersections": (ctypes.c_int, [vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, vp,
                                                 i64, ctypes.POINTER(i64), i32]),
     "pyqsm_point_mesh_distance": (ctypes.c_int, [vp, i64, vp, i64, vp, i64, vp, vp, i32]),
+    "pyqsm_cast_rays_multi": (ctypes.c_int, [vp, i64, vp, i64, vp, i64, vp, vp, vp, i32]),
+    "pyqsm_comm_unique_id": (ctypes.c_int, [vp]),
+    "pyqsm_comm_init_rank": (ctypes.c_int, [vp, i32, i32, i32]),
+    "pyqsm_comm_finalize": (ctypes.c_int, []),
+    "pyqsm_comm_info": (ctypes.c_int, [ctypes.POINTER(i32), ctypes.POINTER(i32),
+                                       ctypes.POINTER(i32)]),
+    "pyqsm_comm_broadcast_dev": (ctypes.c_int, [vp, i64, i32]),
+    "pyqsm_comm_all_gather_dev": (ctypes.c_int, [vp, vp, i64]),
+    "pyqsm_comm_all_reduce_max": (ctypes.c_int, [ctypes.POINTER(dbl)]),
     "pyqsm_dbscan": (ctypes.c_int, [vp, i64, dbl, i32, vp, vp, i32]),
     "pyqsm_dbscan_dev": (ctypes.c_int, [vp, i64, dbl, i32, vp, vp, ctypes.POINTER(i64), i32]),
     "pyqsm_knn": (ctypes.c_int, [vp, i64, i32, i32, vp, vp, i32]),

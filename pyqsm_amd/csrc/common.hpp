@@ -112,6 +112,9 @@ class ApiRange {
 };
 #define PQ_API_RANGE(name) ::pyqsm::ApiRange api_range__(name)
 
+// Destroys the RCCL communicators (multi.hip); called by pyqsm_shutdown.
+void comm_shutdown();
+
 inline int ceil_div(int64_t a, int64_t b) { return static_cast<int>((a + b - 1) / b); }
 
 // Exclusive prefix sum of n int32 values, in place, on the stream (scan.hip).

@@ -298,6 +298,7 @@ int pyqsm_device_count(void) {
 int pyqsm_init(int device) { return ctx_for(device) ? 0 : PYQSM_ENODEV; }
 
 int pyqsm_shutdown(void) {
+  comm_shutdown();
   std::lock_guard<std::mutex> lk(g_mu);
   for (auto& kv : pools()) {
     for (Ctx* c : kv.second.all) {

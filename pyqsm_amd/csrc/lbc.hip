@@ -542,6 +542,15 @@ __global__ __launch_bounds__(256) void k_update_r(int n, const double* __restric
   reduce3_atomic(rr[0], rr[1], rr[2], sc->rr[par]);
 }
 
+// PYQSM_AMG_FIXED=m: every B-solve runs exactly m multigrid-CG iterations (experiment knob)
+static int amg_fixed_iterations() {
+  static const int v = [] {
+    const char* e = getenv("PYQSM_AMG_FIXED");
+    return e ? std::max(0, atoi(e)) : 0;
+  }();
+  return v;
+}
+
 static constexpr int kAmgFirstBurst = 8;  // a 1e-2 solve takes 10-14 iterations: no look before 8
 static constexpr int kAmgBurst = 2;       // then a residual check every 2
 
@@ -817,6 +826,19 @@ static int amg_pcg_f32(Ctx* c, int N, const WorkF& w, AmgHierarchy* H, const flo
   };
   int it = 0;
   bool done = false;
+  if (const int fixed = amg_fixed_iterations()) {
+    // a fixed, even number of iterations and no look at the residual: no host round trip in
+    // the whole B-solve (the outer CG is flexible, an inexact B^-1 costs it a few steps)
+    const int len = std::min<int>((fixed + 1) & ~1, std::max(2, max_it & ~1));
+    {
+      ProfScope ps(c, "lbc_amg_iter", len);
+      PQ_TRY(run_burst(len));
+    }
+    PQ_HIP(hipGetLastError());
+    *iters = len;
+    for (int k = 0; k < 3; ++k) resid[k] = 0.0;
+    return 0;
+  }
   while (!done && it < max_it) {
     int len = it == 0 ? kAmgFirstBurst : kAmgBurst;
     if (len > max_it - it) len = std::max(2, (max_it - it + 1) & ~1);

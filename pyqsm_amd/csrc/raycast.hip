@@ -30,6 +30,8 @@
 
 #include <cmath>
 
+#include "raycast.hpp"
+
 namespace pyqsm {
 
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -1199,6 +1201,16 @@ static int check_sizes(int64_t V, int64_t T, int64_t R) {
   if (R > 0xFFFFFFF0LL) return fail(PYQSM_ERANGE, "more than 2^32 rays per call");
   return 0;
 }
+
+// what multi.hip (the RCCL-sharded sweep) calls on each device
+int ray_expand(Ctx* c, const float* verts, int64_t V, const int32_t* tris, int64_t T, float* tri12) {
+  return expand(c, verts, V, tris, T, reinterpret_cast<TriRec*>(tri12));
+}
+int ray_launch(Ctx* c, const float* tri12, int64_t T, const float* rays, int64_t R, float* t_hit,
+               uint32_t* prim, float* uv) {
+  return launch_cast(c, reinterpret_cast<const TriRec*>(tri12), T, rays, R, t_hit, prim, uv);
+}
+int ray_check_sizes(int64_t V, int64_t T, int64_t R) { return check_sizes(V, T, R); }
 
 }  // namespace pyqsm
 

@@ -1,13 +1,22 @@
 """Multi-GPU ray sweep: rays sharded contiguously over ranks, mesh replicated.
 
-One process per GPU (``torch.distributed``; backend ``nccl`` is RCCL over xGMI on
-ROCm, ``gloo`` on CPU for tests). The only collectives on the data path are a
-broadcast of the mesh (about 18 MB for 500 k triangles) and an all-gather of the
-per-shard results (8 bytes per ray); the sweep itself needs no exchange
-(SURVEY.md §8e). DBSCAN / kNN / skeleton / RANSAC do not shard: replicas only.
+The only collectives on the data path are a broadcast of the mesh (24 MB of expanded
+records for 500 k triangles) and an all-gather of the per-shard results (8 bytes per ray);
+the sweep itself needs no exchange. DBSCAN / kNN / skeleton / RANSAC do
+not shard: replicas only.
 
-``torch`` is imported lazily and only here and in bench.py: it is plumbing for
-the collectives, not part of the compute path.
+Three ways to run it, all with the same shard arithmetic (:func:`shard_bounds`):
+
+* one process, several GPUs: ``hip.cast_rays_multi`` / ``cast_rays(..., n_devices=N)`` —
+  RCCL inside the library (``ncclCommInitAll``), no torch;
+* one process per GPU (torchrun-style): :class:`NativeComm` — an RCCL communicator inside the
+  library per process, its id shipped through a rendezvous the caller provides (a file here,
+  or any ``torch.distributed`` group incl. CPU ``gloo``); every byte of the data path moves
+  through ``pyqsm_comm_*``;
+* any ``torch.distributed`` group (``gloo`` on CPU in the tests): :func:`broadcast_mesh` /
+  :func:`cast_rays_sharded`, generic over the per-shard compute function.
+
+``torch`` is imported lazily and only by the functions that take a ``dist`` argument.
 """
 from __future__ import annotations
 
@@ -78,3 +87,152 @@ def cast_rays_sharded(verts, tris, rays, dist, cast_fn, device=None):
                            for r in range(world)], axis=0)
     return (full[:, 0].copy().view(np.float32), full[:, 1].copy(),
             full[:, 2:].copy().view(np.float32))
+
+
+# --------------------------------------------------------------------------------------
+# RCCL inside the library, one process per GPU
+
+class NativeComm:
+    """The library's own RCCL communicator of this process (``pyqsm_comm_*``).
+
+    ``NativeComm.from_env()`` reads RANK / WORLD_SIZE / LOCAL_RANK (torchrun's variables) and
+    exchanges the 128-byte RCCL id through a file; ``NativeComm.from_torch(dist)`` ships it
+    through an existing ``torch.distributed`` group (``gloo`` is enough: the id is host
+    bytes). Device buffers are :class:`pyqsm_amd.hip.DeviceBuffer`."""
+
+    def __init__(self, id_bytes: bytes, world: int, rank: int, device: int):
+        import ctypes
+        from . import _lib
+        self._lib, self._check = _lib.load(), _lib.check
+        self.world, self.rank, self.device = int(world), int(rank), int(device)
+        buf = (ctypes.c_uint8 * 128).from_buffer_copy(id_bytes)
+        self._check(self._lib.pyqsm_comm_init_rank(buf, self.world, self.rank, self.device))
+
+    @staticmethod
+    def new_id() -> bytes:
+        import ctypes
+        from . import _lib
+        buf = (ctypes.c_uint8 * 128)()
+        _lib.check(_lib.load().pyqsm_comm_unique_id(buf))
+        return bytes(buf)
+
+    @classmethod
+    def from_torch(cls, dist, device: int):
+        rank, world = dist.get_rank(), dist.get_world_size()
+        box = [cls.new_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        return cls(box[0], world, rank, device)
+
+    @classmethod
+    def from_env(cls, device=None, directory: str = "/tmp", timeout_s: float = 120.0):
+        """File rendezvous for single-node launches: rank 0 writes the id to a file named after
+        the launcher's pid and MASTER_PORT, the other ranks wait for it."""
+        import os
+        import time
+        rank = int(os.environ.get("RANK", "0"))
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", str(rank)))
+        path = os.path.join(directory, "pyqsm_comm_%d_%s.id" % (os.getppid(),
+                                                                os.environ.get("MASTER_PORT", "0")))
+        if rank == 0:
+            tmp = path + ".tmp"
+            with open(tmp, "wb") as f:
+                f.write(cls.new_id())
+            os.replace(tmp, path)                       # atomic: readers never see a partial id
+        t0 = time.time()
+        while True:
+            # a file left by an earlier launch with the same pid and port is older than this
+            # launcher's children: ignore anything written before this process started - 5 min
+            if os.path.exists(path) and os.path.getsize(path) == 128 and \
+                    os.path.getmtime(path) > _process_start_time() - 300:
+                with open(path, "rb") as f:
+                    id_bytes = f.read()
+                break
+            if time.time() - t0 > timeout_s:
+                raise TimeoutError(f"no RCCL id at {path} after {timeout_s} s")
+            time.sleep(0.01)
+        comm = cls(id_bytes, world, rank, device)
+        comm.max_over_ranks(0.0)                        # everybody has read the file
+        if rank == 0:
+            try:
+                os.remove(path)
+            except OSError:
+                pass
+        return comm
+
+    def broadcast(self, buf, nbytes: int, root: int = 0) -> None:
+        self._check(self._lib.pyqsm_comm_broadcast_dev(buf.ptr, int(nbytes), int(root)))
+
+    def all_gather(self, send_ptr: int, recv, bytes_per_rank: int) -> None:
+        self._check(self._lib.pyqsm_comm_all_gather_dev(send_ptr, recv.ptr, int(bytes_per_rank)))
+
+    def max_over_ranks(self, x: float) -> float:
+        """Maximum of ``x`` over the ranks; returns once every rank has it (a barrier)."""
+        import ctypes
+        v = ctypes.c_double(float(x))
+        self._check(self._lib.pyqsm_comm_all_reduce_max(ctypes.byref(v)))
+        return v.value
+
+    def barrier(self) -> None:
+        self.max_over_ranks(0.0)
+
+    def close(self) -> None:
+        self._lib.pyqsm_comm_finalize()
+
+
+def _process_start_time() -> float:
+    import os
+    import time
+    try:
+        with open("/proc/self/stat") as f:
+            ticks = int(f.read().rsplit(")", 1)[1].split()[19])
+        with open("/proc/uptime") as f:
+            up = float(f.read().split()[0])
+        return time.time() - up + ticks / os.sysconf("SC_CLK_TCK")
+    except Exception:
+        return time.time()
+
+
+class ShardedSweep:
+    """Config 4's sweep on one rank of a :class:`NativeComm`: the mesh is expanded on rank 0 and
+    broadcast, this rank's contiguous shard of the rays lives in HBM, and every call of
+    :meth:`run` sweeps the shard and all-gathers (t, prim) so that each rank holds the result
+    for ALL rays: ``t_all`` / ``prim_all`` (NumPy, in ray order) after :meth:`results`."""
+
+    def __init__(self, comm: NativeComm, verts, tris, rays_shard, n_rays_total: int):
+        from . import hip
+        self.comm, self.hip = comm, hip
+        self.R = int(n_rays_total)
+        self.sizes = shard_sizes(self.R, comm.world)
+        self.cap = max(self.sizes) if self.sizes else 0
+        dev = comm.device
+        T = int(np.asarray(tris).reshape(-1, 3).shape[0])
+        if comm.rank == 0:
+            self.mesh = hip.DeviceMesh(verts, tris, dev)
+        else:                                            # records arrive over RCCL
+            self.mesh = hip.DeviceMesh.__new__(hip.DeviceMesh)
+            self.mesh.device, self.mesh.n_tris = dev, T
+            self.mesh.records = hip.DeviceBuffer(max(1, T) * 48, dev)
+        comm.broadcast(self.mesh.records, T * 48, root=0)
+        rays_shard = np.ascontiguousarray(rays_shard, dtype=np.float32).reshape(-1, 6)
+        if rays_shard.shape[0] != self.sizes[comm.rank]:
+            raise ValueError("rays_shard does not have this rank's shard size")
+        self.n_local = rays_shard.shape[0]
+        self.d_rays = hip.DeviceBuffer.from_array(rays_shard, dev) if self.n_local else None
+        # one block of [t(cap) | prim(cap)] 32-bit words per rank
+        self.block = hip.DeviceBuffer(max(1, comm.world * 2 * self.cap * 4), dev)
+        hip.sync(dev)
+
+    def run(self) -> None:
+        off = self.block.ptr + self.comm.rank * 2 * self.cap * 4
+        if self.n_local:
+            self.hip.cast_rays_dev(self.mesh, self.d_rays.ptr, self.n_local, off, off + self.cap * 4)
+        self.comm.all_gather(off, self.block, 2 * self.cap * 4)
+
+    def results(self):
+        self.hip.sync(self.comm.device)
+        words = self.block.download((self.comm.world, 2, self.cap), np.uint32)
+        t = np.concatenate([words[r, 0, : self.sizes[r]] for r in range(self.comm.world)])
+        p = np.concatenate([words[r, 1, : self.sizes[r]] for r in range(self.comm.world)])
+        return t.view(np.float32), p

@@ -82,8 +82,9 @@ def create_rays_pinhole(fov_deg, center, eye, up, width_px, height_px) -> np.nda
 class RaycastingScene:
     """The subset of ``open3d.t.geometry.RaycastingScene`` the reference uses."""
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, n_devices: int | None = None):
         self.device = device
+        self.n_devices = n_devices       # not None: sweep on that many GPUs of this process (0 = all)
         self._verts = np.zeros((0, 3), dtype=np.float32)
         self._tris = np.zeros((0, 3), dtype=np.int32)
 
@@ -98,7 +99,10 @@ class RaycastingScene:
     def cast_rays(self, rays) -> dict:
         """{'t_hit' f32 (+inf = miss), 'primitive_ids' u32 (0xFFFFFFFF = miss),
         'primitive_uvs' f32 [...,2], 'geometry_ids' u32}."""
-        t, p, uv = hip.cast_rays(self._verts, self._tris, _np(rays), device=self.device)
+        if self.n_devices is not None:
+            t, p, uv = hip.cast_rays_multi(self._verts, self._tris, _np(rays), self.n_devices)
+        else:
+            t, p, uv = hip.cast_rays(self._verts, self._tris, _np(rays), device=self.device)
         geo = np.where(np.isfinite(t), 0, 0xFFFFFFFF).astype(np.uint32)
         return {"t_hit": t, "primitive_ids": p, "primitive_uvs": uv, "geometry_ids": geo}
 
@@ -155,7 +159,7 @@ def mri(mesh=None, rcs_in=None, n_random: int = 256, grid: int = 64, device: int
 
 
 def cast_rays(tmesh, surf_2d: bool = False, img: bool = False, pinhole_config=pinhole_config,
-              rays=None, device: int = 0) -> dict:
+              rays=None, device: int = 0, n_devices: int | None = None) -> dict:
     """ray_casting.py:262-313: look down on the mesh from 10 units above its centre
     (fov 90 deg, 1280 x 950 px, up (0,1,-1)) and cast one ray per pixel.
 
@@ -167,7 +171,9 @@ def cast_rays(tmesh, surf_2d: bool = False, img: bool = False, pinhole_config=pi
     triangles)`` keeps every triangle whose three vertices were all hit, which on a mesh
     with shared vertices includes triangles no ray reached. (The reference
     returns an undefined name when ``surf_2d`` is false.) ``rays`` overrides the
-    camera, e.g. with parallel sun rays. ``img`` is accepted and ignored."""
+    camera, e.g. with parallel sun rays. ``img`` is accepted and ignored. ``n_devices``
+    (0 = all visible GPUs) shards the rays over that many GPUs of this process through RCCL
+    (``pyqsm_cast_rays_multi``; identical results)."""
     verts, tris = mesh_arrays(tmesh)
     log.info("starting cast rays")
     if rays is None:
@@ -177,7 +183,7 @@ def cast_rays(tmesh, surf_2d: bool = False, img: bool = False, pinhole_config=pi
                "width_px": 640 * 2, "height_px": 475 * 2}             # :272-273
         rays = create_rays_pinhole(**cfg)
     log.info("casting rays")
-    scene = RaycastingScene(device)
+    scene = RaycastingScene(device, n_devices)
     scene.add_triangles((verts, tris))
     ans = scene.cast_rays(rays)
     hit = np.isfinite(ans["t_hit"])                                    # :280

@@ -42,6 +42,10 @@ def test_no_gpu_means_an_error_not_a_fallback():
     with pytest.raises(_lib.PyQSMHipError):
         hip.cast_rays(np.zeros((3, 3), np.float32), np.array([[0, 1, 2]], np.int32),
                       np.zeros((4, 6), np.float32))
+    with pytest.raises(_lib.PyQSMHipError) as e:
+        hip.cast_rays_multi(np.zeros((3, 3), np.float32), np.array([[0, 1, 2]], np.int32),
+                            np.zeros((4, 6), np.float32), n_devices=0)
+    assert e.value.code == -3
 
 
 def test_product_never_imports_the_oracle():
