@@ -60,9 +60,8 @@ def parse():
     ap.add_argument("--no-rays", action="store_true")
     ap.add_argument("--no-knn", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--skel-iters", type=int, default=3,
-                    help="contraction steps of the skeleton section (config 3 runs 20: "
-                         "examples/config3_skeleton.py)")
+    ap.add_argument("--skel-iters", type=int, default=20,
+                    help="contraction steps of the skeleton section (config 3: 20)")
     ap.add_argument("--no-skeleton", action="store_true")
     ap.add_argument("--no-ransac", action="store_true")
     return ap.parse_args()
@@ -142,17 +141,39 @@ def main():
         if dom in tj.get("kernels", {}) and tj.get("points") == n:
             traffic = tj["kernels"][dom]["hbm_bytes_per_launch"]
             traffic_note = tj.get("note", "")
+    step_ms = elapsed / args.steps * 1e3
+    # executed fp64 pair tests of the core pass (profiling level 2 adds a counter; one extra,
+    # untimed call) priced against the FP64 vector peak: SURVEY.md §8d names FP64 VALU as the
+    # binding roof of the neighbourhood kernels (8 flop + 1 compare per candidate pair)
+    hip.prof_enable(2, dev)
+    hip.prof_reset(dev)
+    hip.dbscan_dev(d_xyz.ptr, n, eps, min_pts, d_lab.ptr, d_core.ptr, dev)
+    _, lane_tests = hip.prof_get("core_pair_tests", dev)
+    hip.prof_enable(False, dev)
+    core_ms = kernels["k_core_tiled"]["avg_ms"]
+    core_tflops = 9.0 * lane_tests / (core_ms * 1e-3) / 1e12 if core_ms > 0 else 0.0
     roofline = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "avg_launch_ms": dom_ms,
+                "traffic_GBs": (traffic / (dom_ms * 1e-3) / 1e9) if traffic else None,
+                "step_hbm_frac": DBSCAN_BYTES_PER_POINT * n / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "fp64_valu": {"kernel": "k_core_tiled", "lane_tests_per_launch": lane_tests,
+                              "flop_per_test": 9, "achieved": core_tflops, "peak": FP64_PEAK_TFLOPS,
+                              "unit": "TFLOP/s", "frac": core_tflops / FP64_PEAK_TFLOPS,
+                              "avg_launch_ms": core_ms,
+                              "note": "lane-tests EXECUTED (64 lanes x candidates staged per wave, "
+                                      "counted on the device at profiling level 2), early exits "
+                                      "included; SURVEY's stencil holds ~855 candidates per point"},
                 "note": "algorithmic bytes = 341 B/point (SURVEY.md §8d) x points per launch; "
-                        "the neighbour kernels are FP64-VALU/latency bound, not HBM bound. "
+                        "the neighbour kernels are FP64-VALU/latency bound, not HBM bound "
+                        "(fp64_valu prices the core pass against the vector peak, step_hbm_frac "
+                        "the whole step against HBM, traffic_GBs = counter bytes / launch time). "
                         "traffic: " + traffic_note}
 
     out = {
         "metric": "Mpoints/s DBSCAN (1M-pt synthetic forest, eps=0.1, min_neighbors=10)",
         "value": value, "unit": "Mpoints/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "warmup": args.warmup, "ms_per_step": step_ms,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": f"{n}-point synthetic tree cloud (configs[1]), DBSCAN eps=0.1 "
@@ -167,6 +188,8 @@ def main():
         d_idx = hip.DeviceBuffer(n * k * 4, dev)
         d_d2 = hip.DeviceBuffer(n * k * 8, dev)
         hip.knn_dev(d_xyz.ptr, n, k, True, d_idx.ptr, d_d2.ptr, dev)
+        hip.prof_enable(True, dev)
+        hip.prof_reset(dev)
         barrier()
         reps = max(1, min(args.steps, 5))
         t0 = time.perf_counter()
@@ -174,8 +197,34 @@ def main():
             hip.knn_dev(d_xyz.ptr, n, k, True, d_idx.ptr, d_d2.ptr, dev)
         barrier()
         dt = max_over_ranks(time.perf_counter() - t0)
+        kk = {name: hip.prof_get(name, dev) for name in ("knn_bin", "knn_search", "knn_retry")}
+        hip.prof_enable(False, dev)
+        search_ms = kk["knn_search"][0] / max(kk["knn_search"][1], 1)
+        knn_bytes = (DBSCAN_BYTES_PER_POINT + 12.0 * k) * n      # stencil re-reads + idx/d2 rows out
         out["knn"] = {"k": k, "points_per_gpu": n, "steps": reps, "ms_per_step": dt / reps * 1e3,
-                      "value": world * n / (dt / reps) / 1e6, "unit": "Mpoints/s"}
+                      "value": world * n / (dt / reps) / 1e6, "unit": "Mpoints/s", "dtype": "f64",
+                      "phases_ms": {name: v[0] / reps for name, v in kk.items()},
+                      "roofline": {"kernel": "k_knn_reg<20> (knn_search)", "bound": "hbm",
+                                   "achieved": knn_bytes / (search_ms * 1e-3) / 1e9,
+                                   "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": knn_bytes / (search_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                   "traffic": None, "avg_launch_ms": search_ms,
+                                   "note": "algorithmic bytes = 341 B/point (SURVEY.md §8d, binned "
+                                           "neighbour class) + 12 B x k of result rows; the kernel is "
+                                           "bound by its per-candidate register insertion (FP64 VALU "
+                                           "issue), not by HBM"}}
+        if rank == 0 and world == 1 and not args.no_cpu:
+            from scipy.spatial import cKDTree
+            t0 = time.perf_counter()
+            tree = cKDTree(pts)
+            dd, ii = tree.query(pts, k=k + 1, workers=-1)        # k + 1: the point itself comes first
+            c = time.perf_counter() - t0
+            got = d_idx.download((n, k), np.int32)
+            out["knn"]["cpu_baseline"] = {
+                "value": n / c / 1e6, "unit": "Mpoints/s", "cores": os.cpu_count(), "kind": "reference",
+                "sample": f"scipy.spatial.cKDTree(pts).query(pts, k={k + 1}, workers=-1) on the same {n} "
+                          "points, build included (reconstruction.py:238-240's call; SURVEY.md §8d); "
+                          f"same neighbour sets as GPU: {bool(np.array_equal(np.sort(got, 1), np.sort(ii[:, 1:], 1)))}"}
         d_idx.free()
         d_d2.free()
 
@@ -272,52 +321,84 @@ def main():
     # ------------------------------------------------------------- skeleton (config 3)
     if not args.no_skeleton and world == 1:
         from pyqsm_amd.geometry import skeletonize as skel
-        hip.prof_enable(True, dev)
+        names = ("lap_knn", "lap_fans", "lap_assemble", "lbc_amg_iter", "lbc_amg_build",
+                 "lbc_inner_iter", "lbc_outer_iter")
+        rows = {}
+        for cfac in (3, 7):       # the TOML's active value and the one BASELINE.json quotes
+            hip.prof_enable(True, dev)
+            hip.prof_reset(dev)
+            t0 = time.perf_counter()
+            got, total_shift, steps_done = skel.extract_skeleton(
+                pts, max_iter=args.skel_iters, termination_ratio=0.0, contraction_factor=cfac)
+            wall = time.perf_counter() - t0
+            prof = {kname: hip.prof_get(kname, dev) for kname in names}
+            hip.prof_enable(False, dev)
+            log = got.solve_log
+            rows[f"init_contraction_{cfac}"] = {
+                "contractions": len(steps_done), "wall_s": wall,
+                "s_per_contraction": wall / max(len(steps_done), 1),
+                "laplacian_builds": prof["lap_knn"][1],
+                "laplacian_ms_per_build": sum(prof[q][0] for q in ("lap_knn", "lap_fans", "lap_assemble"))
+                / max(prof["lap_knn"][1], 1),
+                "solve_ms_total": prof["lbc_outer_iter"][0] + prof["lbc_amg_build"][0],
+                "outer_cg_steps": prof["lbc_outer_iter"][1],
+                "multigrid_cg_iterations": prof["lbc_amg_iter"][1],
+                "ms_per_multigrid_cg_iteration": prof["lbc_amg_iter"][0] / max(prof["lbc_amg_iter"][1], 1),
+                "solves_not_converged": sum(1 for q in log if not q["ok"]),
+                "max_true_residual": max((max(q["resid"]) for q in log), default=0.0),
+                "mean_shift_m": float(np.linalg.norm(total_shift, axis=1).mean())}
+        # the three level-0 sparse passes of a multigrid-CG iteration, timed one launch at a time
+        # (profiling level 2) over the first two contractions
+        L0, M0 = skel.point_cloud_laplacian(pts, mollify_factor=1e-6, n_neighbors=20, device=dev)
+        pass_bytes = 8.0 * L0.nnz + 36.0 * n
+        hip.prof_enable(2, dev)
         hip.prof_reset(dev)
-        t0 = time.perf_counter()
-        _, total_shift, steps_done = skel.extract_skeleton(pts, max_iter=args.skel_iters,
-                                                           termination_ratio=0.0)
-        wall = time.perf_counter() - t0
-        prof = {k: hip.prof_get(k, dev) for k in ("lap_knn", "lap_fans", "lap_assemble",
-                                                  "lbc_amg_iter", "lbc_amg_build", "lbc_inner_iter",
-                                                  "lbc_outer_iter")}
+        skel.extract_skeleton(pts, max_iter=2, termination_ratio=0.0, contraction_factor=3)
+        passes = {}
+        for kname in ("k_bspmv_f", "k_down_l0", "k_up_l0"):
+            ms, cnt = hip.prof_get(kname, dev)
+            avg = ms / max(cnt, 1)
+            passes[kname] = {"avg_launch_ms": avg, "launches": cnt,
+                             "achieved": pass_bytes / (avg * 1e-3) / 1e9 if avg > 0 else 0.0,
+                             "frac": pass_bytes / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS if avg > 0 else 0.0}
         hip.prof_enable(False, dev)
+        domk = max(passes, key=lambda q: passes[q]["avg_launch_ms"])
         out["skeleton"] = {
-            "workload": f"{n}-point forest, first {len(steps_done)} of config 3's 20 contractions "
-                        "(extract_skeleton, TOML weights), wall incl. host loop and PCIe",
-            "wall_s": wall, "s_per_contraction": wall / max(len(steps_done), 1),
-            "laplacian_builds": prof["lap_knn"][1],
-            "laplacian_ms_per_build": sum(prof[k][0] for k in ("lap_knn", "lap_fans", "lap_assemble"))
-            / max(prof["lap_knn"][1], 1),
-            "solve_ms_total": prof["lbc_outer_iter"][0] + prof["lbc_amg_build"][0],
-            "outer_cg_steps": prof["lbc_outer_iter"][1],
-            "multigrid_cg_iterations": prof["lbc_amg_iter"][1],
-            "ms_per_multigrid_cg_iteration": prof["lbc_amg_iter"][0] / max(prof["lbc_amg_iter"][1], 1),
-            "jacobi_cg_iterations": prof["lbc_inner_iter"][1],
-            "mean_shift_m": float(np.linalg.norm(total_shift, axis=1).mean()), "dtype": "f64"}
+            "workload": f"{n}-point forest, extract_skeleton with max_iter={args.skel_iters}, "
+                        "termination_ratio=0 (configs[2]), TOML weights; wall incl. host loop and PCIe",
+            "rows": rows, "dtype": "f64 (multigrid preconditioner in f32)",
+            "roofline": {"kernel": domk, "bound": "hbm", "achieved": passes[domk]["achieved"],
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": passes[domk]["frac"],
+                         "traffic": None, "passes": passes, "nnz": int(L0.nnz),
+                         "note": "level-0 sparse passes (fp32 values, 3 right-hand sides as float4 rows) "
+                                 "priced at 8*nnz + 36*N algorithmic bytes each; HIP events around single "
+                                 "launches (profiling level 2) over the first two contractions"}}
         if rank == 0 and not args.no_cpu:
-            # the reference's own solve (three SciPy spsolve calls, skeletonize.py:167-173)
-            # on a bounded sample: the first contraction of a 100 k-point forest
+            # the reference's own solve (three SciPy spsolve calls, skeletonize.py:167-173) on
+            # bounded samples: the first contraction of a 30 k- and a 100 k-point forest
             import oracle
-            ns = min(n, 100_000)
-            sub = synth.forest(ns, seed=0)
-            L, M = skel.point_cloud_laplacian(sub, mollify_factor=1e-6, n_neighbors=20, device=dev)
-            wl = np.full(ns, 3 * 1e3 * np.sqrt(np.mean(M.diagonal())))
-            wh = np.full(ns, 3.0)
-            t0 = time.perf_counter()
-            ref = oracle.least_squares_sparse(sub, L, wl, wh)
-            c = time.perf_counter() - t0
-            t0 = time.perf_counter()
-            got = skel.least_squares_sparse(sub, L, wl, wh, device=dev)
-            g = time.perf_counter() - t0
+            base = {}
+            for ns in (30_000, 100_000):
+                sub = synth.forest(ns, seed=0)
+                L, M = skel.point_cloud_laplacian(sub, mollify_factor=1e-6, n_neighbors=20, device=dev)
+                wl = np.full(ns, 3 * 1e3 * np.sqrt(np.mean(M.diagonal())))
+                wh = np.full(ns, 3.0)
+                t0 = time.perf_counter()
+                ref = oracle.least_squares_sparse(sub, L, wl, wh)
+                c = time.perf_counter() - t0
+                skel.least_squares_sparse(sub, L, wl, wh, device=dev)     # warm
+                t0 = time.perf_counter()
+                got = skel.least_squares_sparse(sub, L, wl, wh, device=dev)
+                g = time.perf_counter() - t0
+                base[ns] = {"cpu_s": c, "gpu_s": g,
+                            "max_rel_diff": float(np.abs(got - ref).max() / np.abs(ref).max())}
             out["skeleton"]["cpu_baseline"] = {
-                "value": ns / c / 1e6, "unit": "Mpoints/s per contraction solve", "cores": 1,
-                "kind": "reference",
-                "sample": f"first contraction solve of a {ns}-point forest by the reference's "
+                "value": 100_000 / base[100_000]["cpu_s"] / 1e6, "unit": "Mpoints/s per contraction solve",
+                "cores": 1, "kind": "reference",
+                "sample": "first contraction solve of a 30 k- and a 100 k-point forest by the reference's "
                           "three scipy spsolve(COLAMD) calls (skeletonize.py:167-173) on the GPU-built "
-                          "Laplacian; same system on the GPU incl. PCIe",
-                "gpu_value": ns / g / 1e6,
-                "max_rel_diff": float(np.abs(got - ref).max() / np.abs(ref).max())}
+                          "Laplacian; value = the 100 k case; gpu_s = same system on the GPU incl. PCIe",
+                "points": base}
 
     # ------------------------------------------------------------- RANSAC circle fit
     if not args.no_ransac and world == 1:
@@ -332,11 +413,23 @@ def main():
         for _ in range(30):
             hip.ransac(ring, triples, "circle", 0.04, dev)
         reps = 20
+        hip.prof_enable(True, dev)
+        hip.prof_reset(dev)
         t0 = time.perf_counter()
         for _ in range(reps):
             res = hip.ransac(ring, triples, "circle", 0.04, dev)
         dt = (time.perf_counter() - t0) / reps
-        out["ransac"] = {"workload": f"{H} circle hypotheses x {nr} points, threshold 0.04 "
+        cnt_ms, cnt_n = hip.prof_get("ransac_count", dev)
+        hip.prof_enable(False, dev)
+        cnt_ms /= max(cnt_n, 1)
+        rtf = 30.0 * H * nr / (cnt_ms * 1e-3) / 1e12 if cnt_ms > 0 else 0.0
+        out["ransac"] = {"roofline": {"kernel": "k_count<0> (ransac_count)", "bound": "fp64-valu",
+                                      "achieved": rtf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                      "frac": rtf / FP64_PEAK_TFLOPS, "traffic": None,
+                                      "avg_launch_ms": cnt_ms,
+                                      "note": "30 flop per point x hypothesis test (SURVEY.md §8d, circle) "
+                                              "over the inlier-count kernel's HIP-event time"},
+                         "workload": f"{H} circle hypotheses x {nr} points, threshold 0.04 "
                                      "(qsm_generation.py:155), host buffers in, inliers out",
                          "ms_per_fit": dt * 1e3, "value": H * nr / dt / 1e6,
                          "unit": "Mpoint-hypothesis tests/s", "inliers": int(len(res[3])),
@@ -362,11 +455,17 @@ def main():
         sk = DBSCAN(eps=eps, min_samples=min_pts).fit(pts)
         c = time.perf_counter() - t0
         same = bool(np.array_equal(sk.labels_, labels))
+        t0 = time.perf_counter()
+        skp = DBSCAN(eps=eps, min_samples=min_pts, n_jobs=-1).fit(pts)
+        cp = time.perf_counter() - t0
         out["cpu_baseline"] = {
             "value": n / c / 1e6, "unit": "Mpoints/s", "cores": 1, "kind": "reference",
             "sample": f"sklearn.cluster.DBSCAN(eps=0.1, min_samples=10).fit on the same {n} "
-                      "points (the call pyQSM makes at math_utils/fit.py:223), one run, "
-                      f"{os.cpu_count()} host cores visible; labels identical to GPU: {same}"}
+                      "points (the call pyQSM makes at math_utils/fit.py:223, default n_jobs), one "
+                      f"run, {os.cpu_count()} host cores visible; labels identical to GPU: {same}",
+            "all_cores": {"value": n / cp / 1e6, "unit": "Mpoints/s", "cores": os.cpu_count(),
+                          "sample": "the same call with n_jobs=-1 (SURVEY.md §8d); labels identical "
+                                    f"to GPU: {bool(np.array_equal(skp.labels_, labels))}"}}
 
     if rank == 0:
         print(json.dumps(out))

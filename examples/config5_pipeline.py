@@ -7,7 +7,12 @@ Laplacian contraction -> RANSAC circles on z-slices -> canopy light simulation.
 Every stage goes through the pyQSM-named wrappers (cluster_DBSCAN, extract_skeleton,
 fit_shape_RANSAC, cast_rays), i.e. through the ctypes C-ABI into the HIP kernels; one JSON
 line with the per-stage times is printed. At --scale 1 this is the 5 M-point / 50 M-ray
-configuration; the ray stage is the only one that shards over several GPUs (bench.py)."""
+configuration.
+
+`--gpus N` (one process, N GPUs of the node): DBSCAN runs on GPU 0, the trees
+(whole clusters) are dealt round-robin over the GPUs for contraction and RANSAC — replicas, no
+collective — and the ray stage shards its rays over the N GPUs through RCCL
+(cast_rays(..., n_devices=N) = pyqsm_cast_rays_multi)."""
 import argparse
 import json
 from concurrent.futures import ThreadPoolExecutor
@@ -31,14 +36,19 @@ def main():
     ap.add_argument("--skeleton-iters", type=int, default=3)
     ap.add_argument("--max-trees", type=int, default=2, help="trees that get skeletonised")
     ap.add_argument("--workers", type=int, default=8,
-                    help="host threads that contract trees concurrently (the library keeps one "
-                         "stream and arena per thread; a 50 k-point tree alone is latency-bound)")
+                    help="host threads PER GPU that contract trees concurrently (the library keeps "
+                         "one stream and arena per thread; a 50 k-point tree alone is latency-bound)")
+    ap.add_argument("--gpus", type=int, default=1, help="GPUs of this node to use (0 = all visible)")
     args = ap.parse_args()
-    _lib.require_gpu(0)
+    n_gpus = args.gpus if args.gpus > 0 else _lib.device_count()
+    if n_gpus > _lib.device_count():
+        raise SystemExit(f"--gpus {n_gpus} but only {_lib.device_count()} visible")
+    for d in range(n_gpus):
+        _lib.require_gpu(d)
     n_points = max(50_000, int(5_000_000 * args.scale))
     n_rays_per_angle = max(100_000, int(10_000_000 * args.scale))
     n_tris = max(20_000, int(500_000 * min(1.0, args.scale * 5)))
-    out = {"points": n_points, "rays": 5 * n_rays_per_angle, "tris": n_tris}
+    out = {"points": n_points, "rays": 5 * n_rays_per_angle, "tris": n_tris, "gpus": n_gpus}
 
     pts = synth.forest(n_points, seed=0)
     t0 = time.perf_counter()
@@ -49,20 +59,22 @@ def main():
     idxs = sorted(idxs, key=len, reverse=True)
 
     t0 = time.perf_counter()
-    def contract(tree):
+    def contract(job):
+        k, tree = job                                   # tree k goes to GPU k mod N (replicas)
         contracted, total_shift, steps = extract_skeleton(pts[tree], max_iter=args.skeleton_iters,
-                                                          termination_ratio=0.0)
+                                                          termination_ratio=0.0, device=k % n_gpus)
         return float(np.linalg.norm(total_shift, axis=1).mean())
 
-    with ThreadPoolExecutor(max_workers=max(1, args.workers)) as pool:
-        shifts = list(pool.map(contract, idxs[: args.max_trees]))
+    with ThreadPoolExecutor(max_workers=max(1, args.workers) * n_gpus) as pool:
+        shifts = list(pool.map(contract, enumerate(idxs[: args.max_trees])))
     out["skeleton_s"] = time.perf_counter() - t0
     out["skeleton_trees"] = len(shifts)
     out["skeleton_workers"] = max(1, args.workers)
     out["mean_contraction_m"] = shifts
 
     t0 = time.perf_counter()
-    def fit_slices(tree):
+    def fit_slices(job):
+        k, tree = job
         cloud = pts[tree]
         found = []
         for z0 in np.arange(0.5, 5.5, 0.5):                 # 0.5 m slices of the stem
@@ -72,13 +84,15 @@ def main():
                 continue
             samples = draw_samples(len(sl), 1000, seed=2)
             mesh, _, inl, r, axis = fit_shape_RANSAC(pts=sl.copy(), shape="circle", threshold=0.04,
-                                                     max_radius=0.3 * 1.75, samples=samples)
+                                                     max_radius=0.3 * 1.75, samples=samples,
+                                                     device=k % n_gpus)
             if mesh is not None:
                 found.append(float(r))
         return found
 
-    with ThreadPoolExecutor(max_workers=max(1, args.workers)) as pool:
-        radii = [r for found in pool.map(fit_slices, idxs[: max(args.max_trees, 4)]) for r in found]
+    with ThreadPoolExecutor(max_workers=max(1, args.workers) * n_gpus) as pool:
+        radii = [r for found in pool.map(fit_slices, enumerate(idxs[: max(args.max_trees, 4)]))
+                 for r in found]
     fits = len(radii)
     out["ransac_s"] = time.perf_counter() - t0
     out["ransac_fits"] = fits
@@ -91,7 +105,7 @@ def main():
     t0 = time.perf_counter()
     lit = []
     for rays in ray_sets:
-        ans = cast_rays((verts, tris), rays=rays)
+        ans = cast_rays((verts, tris), rays=rays, n_devices=n_gpus if n_gpus > 1 else None)
         lit.append(float(ans["hit"].mean()))
     out["rays_s"] = time.perf_counter() - t0
     out["intercepted_fraction"] = lit

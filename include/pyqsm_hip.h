@@ -71,7 +71,11 @@ void pyqsm_free(void* p);
 
 /* HIP-event timers around named kernel groups on the library stream.
  * Disabled by default (zero overhead); bench.py switches them on to measure
- * the dominant kernel's average launch duration live. */
+ * the dominant kernel's average launch duration live. on = 1: phase timers and the
+ * dominant kernels of each path; on = 2: also single kernels inside the solver's
+ * iteration loops (k_bspmv_f, k_down_l0, k_up_l0: adds two event records per launch)
+ * and the pair-test counter of the DBSCAN core pass ("core_pair_tests": launches =
+ * lane-tests executed, ms = 0). */
 int pyqsm_prof_enable(int device, int on);
 int pyqsm_prof_reset(int device);
 /* Sum of elapsed ms and number of launches recorded under `name`

@@ -865,8 +865,11 @@ static int vcycle_impl(Ctx* c, AmgHierarchy* H, const TV* b, TV* x, double* dot)
       break;
     }
     AmgLevel& C = H->lv[size_t(l) + 1];
-    hipLaunchKernelGGL(k_down, g, blk, 0, c->stream, L.n, L.A.indptr, L.A.indices, L.valsdf, L.dinvf, bl,
-                       L.xa, L.r);
+    {
+      ProfScope pk(c, l == 0 ? "k_down_l0" : "k_down_coarse", 1, 2);
+      hipLaunchKernelGGL(k_down, g, blk, 0, c->stream, L.n, L.A.indptr, L.A.indices, L.valsdf, L.dinvf, bl,
+                         L.xa, L.r);
+    }
     hipLaunchKernelGGL(k_restrict, dim3(ceil_div(C.n, 256)), blk, 0, c->stream, C.n, L.mptr, L.members,
                        L.r, C.b);
   }
@@ -875,6 +878,7 @@ static int vcycle_impl(Ctx* c, AmgHierarchy* H, const TV* b, TV* x, double* dot)
     AmgLevel& L = H->lv[size_t(l)];
     AmgLevel& C = H->lv[size_t(l) + 1];
     const dim3 g(ceil_div(L.n, 256));
+    ProfScope pk(c, l == 0 ? "k_up_l0" : "k_up_coarse", 1, 2);
     if (l == 0)
       hipLaunchKernelGGL((k_up<TV, TV>), dot ? dim3(std::min<int64_t>(ceil_div(L.n, 256), 1024)) : g, blk, 0,
                          c->stream, L.n, L.A.indptr, L.A.indices, L.valsf,

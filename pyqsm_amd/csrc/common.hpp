@@ -76,7 +76,7 @@ struct Ctx {
   hipStream_t stream = nullptr;
   Arena arena;
   std::mutex mu;  // calls on one device serialise
-  bool prof = false;
+  int prof = 0;  // 0 off, 1 phase timers, 2 also single kernels inside the solver loops
   std::map<std::string, Timer> timers;
   std::vector<hipEvent_t> event_pool;
   int cu_count = 256;
@@ -90,7 +90,7 @@ Ctx* ctx_for(int device);
 // when profiling is enabled; otherwise does nothing.
 class ProfScope {
  public:
-  ProfScope(Ctx* c, const char* name, int weight = 1);
+  ProfScope(Ctx* c, const char* name, int weight = 1, int level = 1);
   ~ProfScope();
 
  private:

@@ -224,7 +224,7 @@ Ctx* ctx_for(int device) {
       std::lock_guard<std::mutex> lc(c->mu);
       drain_timers(c);
       c->timers.clear();
-      c->prof = false;
+      c->prof = 0;
     }
     t_held.ctx[device] = c;
     return c;
@@ -245,8 +245,8 @@ Ctx* ctx_for(int device) {
 
 // ---- timers ---------------------------------------------------------------
 
-ProfScope::ProfScope(Ctx* c, const char* name, int weight) : c_(c) {
-  if (!c->prof) return;
+ProfScope::ProfScope(Ctx* c, const char* name, int weight, int level) : c_(c) {
+  if (c->prof < level) return;
   t_ = &c->timers[name];
   hipEvent_t a = nullptr, b = nullptr;
   if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
@@ -384,7 +384,7 @@ int pyqsm_prof_enable(int device, int on) {
   Ctx* c = ctx_for(device);
   if (!c) return PYQSM_ENODEV;
   std::lock_guard<std::mutex> lk(c->mu);
-  c->prof = on != 0;
+  c->prof = on < 0 ? 0 : on;
   return 0;
 }
 

@@ -75,7 +75,10 @@ __global__ __launch_bounds__(256) void k_core_tiled(int n, Stencil st, int ncell
                                                     const double* __restrict__ sz, double r2,
                                                     int min_pts, uint8_t* __restrict__ core,
                                                     int32_t* __restrict__ rest,
-                                                    int32_t* __restrict__ rest_cnt) {
+                                                    int32_t* __restrict__ rest_cnt,
+                                                    unsigned long long* __restrict__ tests /*may be null:
+                                                    [256] slots, candidates staged per wave (x 64 lanes
+                                                    = lane-tests executed)*/) {
   __shared__ TileLds L;
   // wave-uniform quantities are forced into SGPRs so that the loops below are scalar
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -88,6 +91,7 @@ __global__ __launch_bounds__(256) void k_core_tiled(int n, Stencil st, int ncell
   int cnt = 0;  // (starting lanes of sub-cells with >= min_pts points as "decided" gained nothing)
   bool deferred = false;
   int chunks = 0;
+  int staged = 0;  // wave-uniform: candidates this wave tested its 64 lanes against
   if (t.total > kTileMax) {
     // The wave's points straddle distant cells (end of one grid layer, start of the next):
     // the linear intervals would sweep whole layers. Take the distinct cells of the wave
@@ -115,6 +119,7 @@ __global__ __launch_bounds__(256) void k_core_tiled(int n, Stencil st, int ncell
               L.z[w][lane] = sz[q];
             }
             __builtin_amdgcn_wave_barrier();
+            staged += m;
             if (mine)
               for (int j = 0; j < m; ++j)
                 cnt += sqdist(x, y, z, L.x[w][j], L.y[w][j], L.z[w][j]) <= r2;
@@ -135,6 +140,7 @@ __global__ __launch_bounds__(256) void k_core_tiled(int n, Stencil st, int ncell
           L.z[w][lane] = sz[q];
         }
         __builtin_amdgcn_wave_barrier();
+        staged += m;
 #pragma unroll 4
         for (int j = 0; j < m; ++j)
           cnt += sqdist(x, y, z, L.x[w][j], L.y[w][j], L.z[w][j]) <= r2;
@@ -161,6 +167,7 @@ __global__ __launch_bounds__(256) void k_core_tiled(int n, Stencil st, int ncell
     }
   }
   if (live && cnt >= 0) core[p] = cnt >= min_pts;
+  if (tests && lane == 0) atomicAdd(tests + (blockIdx.x & 255), static_cast<unsigned long long>(staged));
 }
 
 // The stragglers of k_core_tiled, one WAVE each: 64 candidates of the stencil per step,
@@ -726,10 +733,23 @@ static int dbscan_device(Ctx* c, const double* xyz, int64_t n, double eps, int32
   {
     ProfScope ps(c, "dbscan_core");
     PQ_HIP(hipMemsetAsync(list_cnt + 1, 0, 4, c->stream));
+    unsigned long long* d_tests = nullptr;
+    if (c->prof >= 2) {
+      PQ_TRY(c->arena.get(256, &d_tests));
+      PQ_HIP(hipMemsetAsync(d_tests, 0, 256 * 8, c->stream));
+    }
     {
       ProfScope pk(c, "k_core_tiled");
       hipLaunchKernelGGL(k_core_tiled, grid, block, 0, c->stream, N, st, int(g.ncell), g.start,
-                         g.cell_of, g.sx, g.sy, g.sz, r2, min_pts, core, rest, list_cnt + 1);
+                         g.cell_of, g.sx, g.sy, g.sz, r2, min_pts, core, rest, list_cnt + 1, d_tests);
+    }
+    if (d_tests) {  // profiling level 2 only: read the counter back (synchronises)
+      unsigned long long h[256];
+      PQ_HIP(hipMemcpyAsync(h, d_tests, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+      PQ_HIP(hipStreamSynchronize(c->stream));
+      unsigned long long tot = 0;
+      for (unsigned long long v : h) tot += v;
+      c->timers["core_pair_tests"].launches += int64_t(tot) * 64;  // lane-tests executed
     }
     hipLaunchKernelGGL(k_core_rest, dim3(std::min<int64_t>(8192, ceil_div(n, 64))), block, 0, c->stream,
                        rest, list_cnt + 1, st, g.start, g.cell_of, g.sx, g.sy, g.sz, r2, min_pts, core);

@@ -794,7 +794,10 @@ static int amg_pcg_f32(Ctx* c, int N, const WorkF& w, AmgHierarchy* H, const flo
   for (int k = 0; k < 3; ++k) resid[k] = 1.0;
   *iters = 0;
   auto iteration = [&](int par) -> int {
-    hipLaunchKernelGGL(k_bspmv_f, rgrid, block, 0, c->stream, N, ip, ix, bv, w.dir, w.q, w.sc, par);
+    {
+      ProfScope pk(c, "k_bspmv_f", 1, 2);
+      hipLaunchKernelGGL(k_bspmv_f, rgrid, block, 0, c->stream, N, ip, ix, bv, w.dir, w.q, w.sc, par);
+    }
     hipLaunchKernelGGL(k_update_r_f, rgrid, block, 0, c->stream, N, w.dir, w.q, y, w.r, w.sc, par);
     PQ_TRY(amg_vcycle_f32(c, H, w.r, w.z, w.sc->rz[par ^ 1]));
     hipLaunchKernelGGL(k_direction_f, grid, block, 0, c->stream, N, w.z, w.dir, w.sc, par);

@@ -31,7 +31,7 @@ def _select(pcd, pts, idx):
 
 def cluster_plus(pcd, eps=config["trunk"]["cluster_eps"], min_points=config["trunk"]["cluster_nn"],
                  draw_result=True, color_clusters=True, from_points=True, return_pcds=True,
-                 ransac=False):
+                 ransac=False, device: int = 0):
     """point_cloud_processing.py:169-203. ``from_points=True`` (the default) means
     ``pcd`` is an array of points. Returns the list of sub-clouds, one per label in
     ascending label order (noise -1 first when present), or ``{label: indices}``
@@ -42,7 +42,7 @@ def cluster_plus(pcd, eps=config["trunk"]["cluster_eps"], min_points=config["tru
     pts = as_points(pcd)
     if from_points:
         pcd = PointCloud(pts)
-    labels, _ = hip.dbscan(pts, eps, min_points)
+    labels, _ = hip.dbscan(pts, eps, min_points, device=device)
     unique_lbs, counts = np.unique(labels, return_counts=True)
     log.info(f"point cloud has {counts} clusters")
     label_to_cluster = {ulabel: np.where(labels == ulabel)[0] for ulabel in unique_lbs}
@@ -52,11 +52,12 @@ def cluster_plus(pcd, eps=config["trunk"]["cluster_eps"], min_points=config["tru
 
 
 def cluster_and_get_largest(pcd, eps=config["trunk"]["cluster_eps"],
-                            min_points=config["trunk"]["cluster_nn"], draw_clusters=False):
+                            min_points=config["trunk"]["cluster_nn"], draw_clusters=False,
+                            device: int = 0):
     """point_cloud_processing.py:205-218: the sub-cloud of the most populous label
     (noise counts as a label, as in the reference)."""
     pts = as_points(pcd)
-    labels, _ = hip.dbscan(pts, eps, min_points)
+    labels, _ = hip.dbscan(pts, eps, min_points, device=device)
     log.info(f"point cloud has {labels.max() + 1 if len(labels) else 0} clusters")
     if len(labels) == 0:
         return _select(pcd, pts, np.zeros(0, dtype=np.int64))

@@ -76,8 +76,9 @@ def sync(device: int = 0) -> None:
     check(_lib.load().pyqsm_sync(int(device)))
 
 
-def prof_enable(on: bool, device: int = 0) -> None:
-    check(_lib.load().pyqsm_prof_enable(int(device), int(bool(on))))
+def prof_enable(on, device: int = 0) -> None:
+    """0 / False off; 1 / True phase timers; 2 also single solver kernels and counters."""
+    check(_lib.load().pyqsm_prof_enable(int(device), int(on)))
 
 
 def prof_reset(device: int = 0) -> None:

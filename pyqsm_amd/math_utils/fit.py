@@ -75,12 +75,14 @@ def _group_labels(labels, core, pts_idxs):
     return unique_labels, idxs, noise
 
 
-def cluster_DBSCAN(pts_idxs, points, eps, min_pts):
-    """fit.py:217-250. Returns ``(unique_labels, idxs, noise)``:
+def cluster_DBSCAN(pts_idxs, points, eps, min_pts, device: int = 0):
+    """fit.py:217-250 (``device`` is this package's addition: the GPU to run on, so that whole
+    clusters can be distributed over the GPUs of a node). Returns
+    ``(unique_labels, idxs, noise)``:
     ``unique_labels`` the set of labels (including -1 when present); ``idxs`` one
     array of caller indices per non-noise label, in set-iteration order, holding
     that cluster's CORE samples only; ``noise`` the caller indices with label -1."""
-    labels, core = hip.dbscan(as_points(points), eps, min_pts)
+    labels, core = hip.dbscan(as_points(points), eps, min_pts, device=device)
     pts_idxs = np.asarray(pts_idxs)
     unique_labels, idxs, noise = _group_labels(labels, core.astype(bool), pts_idxs)
     num_clusters = len(unique_labels) - (1 if -1 in unique_labels else 0)

@@ -64,7 +64,8 @@ def test_signatures_match_the_reference():
 
     def names(f):
         return list(inspect.signature(f).parameters)
-    assert names(cluster_DBSCAN) == ["pts_idxs", "points", "eps", "min_pts"]
+    # the reference's parameters first and in order; this package only appends (device=...)
+    assert names(cluster_DBSCAN) == ["pts_idxs", "points", "eps", "min_pts", "device"]
     assert names(fit_shape_RANSAC)[:7] == ["pcd", "pts", "threshold", "lower_bound", "max_radius",
                                            "align_to_z", "shape"]
     assert names(least_squares_sparse)[:5] == ["pts", "L", "laplacian_weighting",
@@ -74,7 +75,7 @@ def test_signatures_match_the_reference():
         "contraction_factor", "attraction_factor", "max_contraction", "max_attraction",
         "step_wise_contraction_amplification", "cmag_save_file", "min_contraction"]
     assert names(cluster_plus) == ["pcd", "eps", "min_points", "draw_result", "color_clusters",
-                                   "from_points", "return_pcds", "ransac"]
+                                   "from_points", "return_pcds", "ransac", "device"]
     assert names(cast_rays)[:4] == ["tmesh", "surf_2d", "img", "pinhole_config"]
     sig = inspect.signature(fit_shape_RANSAC)
     assert sig.parameters["threshold"].default == 0.1 and sig.parameters["shape"].default == "circle"
