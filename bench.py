@@ -134,7 +134,9 @@ def main():
     dom_ms = kernels[dom]["avg_ms"]
     achieved = DBSCAN_BYTES_PER_POINT * n / (dom_ms * 1e-3) / 1e9
     traffic, traffic_note = None, "no PMC summary found under profiles/"
-    tpath = os.path.join(ROOT, "profiles", "r01_dbscan_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r02_dbscan_traffic.json")
+    if not os.path.exists(tpath):
+        tpath = os.path.join(ROOT, "profiles", "r01_dbscan_traffic.json")
     if os.path.exists(tpath):                        # written from the rocprofv3 --pmc passes
         with open(tpath) as f:
             tj = json.load(f)

@@ -706,8 +706,13 @@ static int dbscan_device(Ctx* c, const double* xyz, int64_t n, double eps, int32
     ProfScope ps(c, "dbscan_bin");
     // a hair wider than eps: rounding of the cell index can then never put two
     // points that are within eps of each other two cells apart
-    PQ_TRY(build_grid(c, xyz, n, eps * (1.0 + 1.0 / 1048576.0), int64_t(1) << 28, &g));
-    PQ_TRY(subsort_octants(c, &g, n, &sub));
+    const char* old = getenv("PYQSM_DBSCAN_BIN");  // "2pass": the round-1 binning (A/B comparisons)
+    if (old && !strcmp(old, "2pass")) {
+      PQ_TRY(build_grid(c, xyz, n, eps * (1.0 + 1.0 / 1048576.0), int64_t(1) << 28, &g));
+      PQ_TRY(subsort_octants(c, &g, n, &sub));
+    } else {
+      PQ_TRY(build_grid_octants(c, xyz, n, eps * (1.0 + 1.0 / 1048576.0), int64_t(1) << 28, &g, &sub));
+    }
   }
   // the sub-cell shortcuts need cells of edge eps (not doubled to fit the dense grid)
   const bool fine = g.cell <= eps * (1.0 + 1.0 / 524288.0);

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void k_bbox(const double* __restrict__ xyz, in
 
 __global__ __launch_bounds__(256) void k_bbox_fold(const unsigned long long* __restrict__ part,
                                                    int nblk, unsigned long long* __restrict__ out) {
-  __shared__ unsigned long long red[256][6];
+  __shared__ unsigned long long red[4][6];
   unsigned long long v[6] = {~0ull, ~0ull, ~0ull, 0, 0, 0};
   for (int b = threadIdx.x; b < nblk; b += 256)
 #pragma unroll
@@ -72,11 +72,19 @@ __global__ __launch_bounds__(256) void k_bbox_fold(const unsigned long long* __r
       v[a] = a < 3 ? (o < v[a] ? o : v[a]) : (o > v[a] ? o : v[a]);
     }
 #pragma unroll
-  for (int a = 0; a < 6; ++a) red[threadIdx.x][a] = v[a];
+  for (int a = 0; a < 6; ++a)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const unsigned long long o = __shfl_down(v[a], off, 64);
+      v[a] = a < 3 ? (o < v[a] ? o : v[a]) : (o > v[a] ? o : v[a]);
+    }
+  if ((threadIdx.x & 63) == 0)
+#pragma unroll
+    for (int a = 0; a < 6; ++a) red[threadIdx.x >> 6][a] = v[a];
   __syncthreads();
   if (threadIdx.x < 6) {
     unsigned long long r = red[0][threadIdx.x];
-    for (int q = 1; q < 256; ++q) {
+    for (int q = 1; q < 4; ++q) {
       const unsigned long long o = red[q][threadIdx.x];
       r = threadIdx.x < 3 ? (o < r ? o : r) : (o > r ? o : r);
     }
@@ -383,6 +391,354 @@ int subsort_octants(Ctx* c, DevGrid* g, int64_t n, SubCells* sub) {
   g->sx = sx2;
   g->sy = sy2;
   g->sz = sz2;
+  return 0;
+}
+
+// ---- grid + octant sub-cells in one pass (DBSCAN's binning) ------------------------------
+
+struct AxisMap {  // raw slab index -> compressed slab index (+1 for the border); null = identity
+  const int32_t *x, *y, *z;
+};
+
+struct RawCell {
+  int cx, cy, cz, oct;
+};
+
+// raw interior coordinates (0-based, clamped) and the octant inside the raw cell
+__device__ __forceinline__ RawCell raw_cell(const GridParams& g, int rx, int ry, int rz, double x,
+                                            double y, double z) {
+  // positions in half cells; the cell is half of that, the octant its parity
+  int hx = int(floor((x - g.minx) * (2.0 * g.inv_cell)));
+  int hy = int(floor((y - g.miny) * (2.0 * g.inv_cell)));
+  int hz = int(floor((z - g.minz) * (2.0 * g.inv_cell)));
+  int cx = int(floor((x - g.minx) * g.inv_cell));
+  int cy = int(floor((y - g.miny) * g.inv_cell));
+  int cz = int(floor((z - g.minz) * g.inv_cell));
+  cx = cx < 0 ? 0 : (cx > rx - 1 ? rx - 1 : cx);
+  cy = cy < 0 ? 0 : (cy > ry - 1 ? ry - 1 : cy);
+  cz = cz < 0 ? 0 : (cz > rz - 1 ? rz - 1 : cz);
+  // octant relative to the cell the point was binned into (as k_sub_count: h - 2 c < 1 ? 0 : 1)
+  const int ox = hx - 2 * cx < 1 ? 0 : 1, oy = hy - 2 * cy < 1 ? 0 : 1, oz = hz - 2 * cz < 1 ? 0 : 1;
+  return RawCell{cx, cy, cz, ox | (oy << 1) | (oz << 2)};
+}
+
+// which raw slabs hold a point (plain stores of 1: racing stores of the same value)
+__global__ __launch_bounds__(256) void k_axis_occ(const double* __restrict__ xyz, int64_t n,
+                                                  GridParams g, int rx, int ry, int rz,
+                                                  int32_t* __restrict__ ox, int32_t* __restrict__ oy,
+                                                  int32_t* __restrict__ oz) {
+  int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+  if (i >= n) return;
+  const RawCell r = raw_cell(g, rx, ry, rz, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
+  ox[r.cx] = 1;
+  oy[r.cy] = 1;
+  oz[r.cz] = 1;
+}
+
+// keep[i] = slab i is occupied, or is the first empty slab after an occupied one
+__global__ __launch_bounds__(256) void k_axis_keep(int m, const int32_t* __restrict__ occ,
+                                                   int32_t* __restrict__ keep /*[m + 1]*/) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i > m) return;
+  keep[i] = i < m ? ((occ[i] || (i > 0 && occ[i - 1])) ? 1 : 0) : 0;
+}
+
+// after the scan: compressed index of every raw slab, shifted by the border cell
+__global__ __launch_bounds__(256) void k_axis_shift(int m, int32_t* __restrict__ map) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < m) map[i] += 1;
+}
+
+template <bool MAPPED>
+__global__ __launch_bounds__(256) void k_cell_count_oct(const double* __restrict__ xyz, int64_t n,
+                                                        GridParams g, int rx, int ry, int rz, AxisMap am,
+                                                        int32_t* __restrict__ counts,
+                                                        int32_t* __restrict__ cell_tmp,
+                                                        int32_t* __restrict__ rank_tmp) {
+  int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+  if (i >= n) return;
+  const RawCell r = raw_cell(g, rx, ry, rz, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
+  const int cx = MAPPED ? am.x[r.cx] : r.cx + 1, cy = MAPPED ? am.y[r.cy] : r.cy + 1,
+            cz = MAPPED ? am.z[r.cz] : r.cz + 1;
+  const int c = (cz * g.ny + cy) * g.nx + cx;
+  cell_tmp[i] = c;
+  rank_tmp[i] = (atomicAdd(&counts[c], 1) << 3) | r.oct;  // arrival rank in the cell, octant
+}
+
+// One 32-byte record per point to its cell-sorted position: coordinates, original index,
+// cell * 8 + octant. (Scattering only (index, key) and gathering the coordinates in the ordering
+// pass cost 13 + 51 us per million points: a million random 24-byte reads. With the coordinates
+// in the record the ordering pass reads and writes whole lines.)
+struct alignas(32) PointRec {
+  double x, y, z;
+  int32_t idx, key;
+};
+
+__global__ __launch_bounds__(256) void k_scatter_keys(const double* __restrict__ xyz, int64_t n,
+                                                      const int32_t* __restrict__ start,
+                                                      const int32_t* __restrict__ cell_tmp,
+                                                      const int32_t* __restrict__ rank_tmp,
+                                                      PointRec* __restrict__ keyed) {
+  int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
+  if (i >= n) return;
+  const int c = cell_tmp[i], ro = rank_tmp[i];
+  PointRec r;
+  r.x = xyz[3 * i];
+  r.y = xyz[3 * i + 1];
+  r.z = xyz[3 * i + 2];
+  r.idx = int(i);
+  r.key = (c << 3) | (ro & 7);
+  keyed[start[c] + (ro >> 3)] = r;
+}
+
+static constexpr int kBigCell = 128;  // cells with more points are ordered by a block, not per point
+
+// One thread per cell-sorted position p: the final position of its point inside the cell's run,
+// ordered by octant (stable in arrival rank), from the octant bits of the run itself; the run's
+// first thread also writes the eight sub-cell records. Cells with more than kBigCell points are
+// listed for k_order_big (a per-point walk would be quadratic in the cell's size).
+__global__ __launch_bounds__(256) void k_order_cells(int n, const int32_t* __restrict__ start,
+                                                     const PointRec* __restrict__ keyed,
+                                                     int32_t* __restrict__ order,
+                                                     int32_t* __restrict__ cell_of,
+                                                     int32_t* __restrict__ sub_of,
+                                                     double* __restrict__ sx, double* __restrict__ sy,
+                                                     double* __restrict__ sz,
+                                                     int32_t* __restrict__ sub_cnt,
+                                                     int32_t* __restrict__ sub_beg,
+                                                     int4* __restrict__ rec,
+                                                     int32_t* __restrict__ big_list,
+                                                     int32_t* __restrict__ big_cnt) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= n) return;
+  const PointRec me = keyed[p];
+  const int c = me.key >> 3, o = me.key & 7;
+  const int b = start[c], e = start[c + 1];
+  if (e - b > kBigCell) {
+    if (p == b) big_list[atomicAdd(big_cnt, 1)] = c;
+    return;
+  }
+  int less = 0, same_before = 0;
+  int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const bool first = p == b;
+  for (int q = b; q < e; ++q) {
+    const int oq = keyed[q].key & 7;
+    less += oq < o;
+    same_before += (oq == o) & (q < p);
+    if (first) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) cnt[k] += oq == k;
+    }
+  }
+  const int f = b + less + same_before;
+  order[f] = me.idx;
+  cell_of[f] = c;
+  sub_of[f] = b * 8 + o;
+  sx[f] = me.x;
+  sy[f] = me.y;
+  sz[f] = me.z;
+  if (first) {
+    int run = b;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      sub_beg[size_t(b) * 8 + k] = run;
+      sub_cnt[size_t(b) * 8 + k] = cnt[k];
+      rec[size_t(b) * 8 + k] = make_int4(run, cnt[k], -1, 0);
+      run += cnt[k];
+    }
+  }
+}
+
+// A block per big cell: stable counting sort of the run by octant (two sweeps over the run).
+__global__ __launch_bounds__(256) void k_order_big(const int32_t* __restrict__ big_list,
+                                                   const int32_t* __restrict__ big_cnt,
+                                                   const int32_t* __restrict__ start,
+                                                   const PointRec* __restrict__ keyed,
+                                                   int32_t* __restrict__ order,
+                                                   int32_t* __restrict__ cell_of,
+                                                   int32_t* __restrict__ sub_of,
+                                                   double* __restrict__ sx, double* __restrict__ sy,
+                                                   double* __restrict__ sz,
+                                                   int32_t* __restrict__ sub_cnt,
+                                                   int32_t* __restrict__ sub_beg,
+                                                   int4* __restrict__ rec) {
+  __shared__ int tot[8], base[8], wcnt[4][8];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int nbig = *big_cnt;  // usually 0: the launch is then a few idle blocks
+  for (int bi = blockIdx.x; bi < nbig; bi += gridDim.x) {  // block-uniform
+  const int c = big_list[bi];
+  const int b = start[c], e = start[c + 1];
+  __syncthreads();
+  if (threadIdx.x < 8) tot[threadIdx.x] = 0;
+  __syncthreads();
+  // sweep 1: octant totals
+  int loc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int q = b + threadIdx.x; q < e; q += 256) {
+    const int oq = keyed[q].key & 7;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) loc[k] += oq == k;
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    int v = loc[k];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (lane == 0 && v) atomicAdd(&tot[k], v);  // LDS, four adders
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = b;
+    for (int k = 0; k < 8; ++k) {
+      base[k] = run;
+      sub_beg[size_t(b) * 8 + k] = run;
+      sub_cnt[size_t(b) * 8 + k] = tot[k];
+      rec[size_t(b) * 8 + k] = make_int4(run, tot[k], -1, 0);
+      run += tot[k];
+    }
+  }
+  __syncthreads();
+  // sweep 2: chunks of 256 in run order; rank inside the chunk by ballots, chunk bases advance
+  for (int q0 = b; q0 < e; q0 += 256) {
+    const int q = q0 + threadIdx.x;
+    const bool live = q < e;
+    PointRec me;
+    me.key = 0;
+    if (live) me = keyed[q];
+    const int o = me.key & 7;
+    int before = 0;  // same octant, earlier lane of this wave
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const unsigned long long m = __ballot(live && o == k);
+      if (lane == 0) wcnt[w][k] = __popcll(m);
+      if (o == k) before = __popcll(m & ((1ull << lane) - 1ull));
+    }
+    __syncthreads();
+    if (live) {
+      int f = base[o] + before;
+      for (int ww = 0; ww < w; ++ww) f += wcnt[ww][o];
+      order[f] = me.idx;
+      cell_of[f] = c;
+      sub_of[f] = b * 8 + o;
+      sx[f] = me.x;
+      sy[f] = me.y;
+      sz[f] = me.z;
+    }
+    __syncthreads();
+    if (threadIdx.x < 8)
+      base[threadIdx.x] += wcnt[0][threadIdx.x] + wcnt[1][threadIdx.x] + wcnt[2][threadIdx.x] +
+                           wcnt[3][threadIdx.x];
+    __syncthreads();
+  }
+  }
+}
+
+int build_grid_octants(Ctx* c, const double* xyz, int64_t n, double min_cell, int64_t max_cells,
+                       DevGrid* g, SubCells* sub) {
+  if (n <= 0) return fail(PYQSM_EINVAL, "build_grid_octants: empty cloud");
+  if (n > (int64_t(1) << 27)) return fail(PYQSM_ERANGE, "octant sub-cells: more than 2^27 points");
+  if (max_cells > (int64_t(1) << 28)) max_cells = int64_t(1) << 28;  // cell * 8 + octant in 31 bits
+  if (!(min_cell > 0) || !std::isfinite(min_cell))
+    return fail(PYQSM_EINVAL, "cell edge must be positive and finite");
+  double mn[3], mx[3];
+  PQ_TRY(cloud_bbox(c, xyz, n, mn, mx));
+  const dim3 grid(ceil_div(n, 256)), blk(256);
+  double cell = min_cell;
+  int raw[3], dims[3];
+  AxisMap am{nullptr, nullptr, nullptr};
+  bool mapped = false;
+  for (;;) {
+    double tot = 1.0;
+    bool ok = true;
+    for (int a = 0; a < 3; ++a) {
+      const double d = std::floor((mx[a] - mn[a]) / cell) + 1.0;  // interior slabs
+      if (!(d < 2.0e9)) ok = false;
+      raw[a] = ok ? int(d) : 0;
+      dims[a] = raw[a] + 2;
+      tot *= d + 2.0;
+    }
+    if (ok && tot <= double(max_cells)) break;
+    // too many cells of this edge: drop the empty slabs (per axis) before giving up on the edge
+    const int64_t raw_sum = ok ? int64_t(raw[0]) + raw[1] + raw[2] : int64_t(1) << 40;
+    if (raw_sum <= (int64_t(1) << 27)) {
+      GridParams gp{mn[0], mn[1], mn[2], 1.0 / cell, 0, 0, 0};
+      int32_t* occ[3];
+      int32_t* map[3];
+      for (int a = 0; a < 3; ++a) {
+        PQ_TRY(c->arena.get(size_t(raw[a]) + 1, &occ[a]));
+        PQ_TRY(c->arena.get(size_t(raw[a]) + 1, &map[a]));
+        PQ_HIP(hipMemsetAsync(occ[a], 0, (size_t(raw[a]) + 1) * 4, c->stream));
+      }
+      hipLaunchKernelGGL(k_axis_occ, grid, blk, 0, c->stream, xyz, n, gp, raw[0], raw[1], raw[2], occ[0],
+                         occ[1], occ[2]);
+      double ctot = 1.0;
+      for (int a = 0; a < 3; ++a) {
+        hipLaunchKernelGGL(k_axis_keep, dim3(ceil_div(raw[a] + 1, 256)), blk, 0, c->stream, raw[a], occ[a],
+                           map[a]);
+        PQ_HIP(hipGetLastError());
+        PQ_TRY(exclusive_scan_i32(c, map[a], int64_t(raw[a]) + 1));
+        int32_t kept = 0;
+        PQ_HIP(hipMemcpyAsync(&kept, map[a] + raw[a], 4, hipMemcpyDeviceToHost, c->stream));
+        PQ_HIP(hipStreamSynchronize(c->stream));
+        hipLaunchKernelGGL(k_axis_shift, dim3(ceil_div(raw[a], 256)), blk, 0, c->stream, raw[a], map[a]);
+        dims[a] = kept + 2;
+        ctot *= double(dims[a]);
+      }
+      PQ_HIP(hipGetLastError());
+      if (ctot <= double(max_cells)) {
+        am = AxisMap{map[0], map[1], map[2]};
+        mapped = true;
+        break;
+      }
+    }
+    cell *= 2.0;
+  }
+  g->minx = mn[0];
+  g->miny = mn[1];
+  g->minz = mn[2];
+  g->cell = cell;
+  g->inv_cell = 1.0 / cell;
+  g->nx = dims[0];
+  g->ny = dims[1];
+  g->nz = dims[2];
+  g->ncell = int64_t(dims[0]) * dims[1] * dims[2];
+  int32_t *cell_tmp, *rank_tmp, *big_list, *big_cnt;
+  PointRec* keyed;
+  PQ_TRY(c->arena.get(size_t(g->ncell) + 1, &g->start));
+  PQ_TRY(c->arena.get(size_t(n), &g->order));
+  PQ_TRY(c->arena.get(size_t(n), &g->cell_of));
+  PQ_TRY(c->arena.get(size_t(n), &g->sx));
+  PQ_TRY(c->arena.get(size_t(n), &g->sy));
+  PQ_TRY(c->arena.get(size_t(n), &g->sz));
+  PQ_TRY(c->arena.get(size_t(n), &cell_tmp));
+  PQ_TRY(c->arena.get(size_t(n), &rank_tmp));
+  PQ_TRY(c->arena.get(size_t(n), &keyed));
+  PQ_TRY(c->arena.get(size_t(n) * 8, &sub->sub_cnt));
+  PQ_TRY(c->arena.get(size_t(n) * 8, &sub->sub_beg));
+  PQ_TRY(c->arena.get(size_t(n), &sub->sub_of));
+  PQ_TRY(c->arena.get(size_t(n) * 8, &sub->rec));
+  PQ_TRY(c->arena.get(size_t(n) / kBigCell + 2, &big_list));
+  PQ_TRY(c->arena.get(1, &big_cnt));
+  PQ_HIP(hipMemsetAsync(g->start, 0, (size_t(g->ncell) + 1) * 4, c->stream));
+  PQ_HIP(hipMemsetAsync(big_cnt, 0, 4, c->stream));
+  GridParams gp{g->minx, g->miny, g->minz, g->inv_cell, g->nx, g->ny, g->nz};
+  if (mapped)
+    hipLaunchKernelGGL(k_cell_count_oct<true>, grid, blk, 0, c->stream, xyz, n, gp, raw[0], raw[1], raw[2],
+                       am, g->start, cell_tmp, rank_tmp);
+  else
+    hipLaunchKernelGGL(k_cell_count_oct<false>, grid, blk, 0, c->stream, xyz, n, gp, raw[0], raw[1], raw[2],
+                       am, g->start, cell_tmp, rank_tmp);
+  PQ_HIP(hipGetLastError());
+  PQ_TRY(exclusive_scan_i32(c, g->start, g->ncell + 1));
+  hipLaunchKernelGGL(k_scatter_keys, grid, blk, 0, c->stream, xyz, n, g->start, cell_tmp, rank_tmp, keyed);
+  hipLaunchKernelGGL(k_order_cells, grid, blk, 0, c->stream, int(n), g->start, keyed, g->order,
+                     g->cell_of, sub->sub_of, g->sx, g->sy, g->sz, sub->sub_cnt, sub->sub_beg, sub->rec,
+                     big_list, big_cnt);
+  PQ_HIP(hipGetLastError());
+  // cells with more than kBigCell points (none on a scan at eps ~ 10 x the point spacing): a fixed
+  // grid reads their number on the device, so that no host round trip is needed
+  hipLaunchKernelGGL(k_order_big, dim3(unsigned(std::min<int64_t>(n / kBigCell + 1, 2048))), blk, 0,
+                     c->stream, big_list, big_cnt, g->start, keyed, g->order, g->cell_of, sub->sub_of,
+                     g->sx, g->sy, g->sz, sub->sub_cnt, sub->sub_beg, sub->rec);
+  PQ_HIP(hipGetLastError());
   return 0;
 }
 

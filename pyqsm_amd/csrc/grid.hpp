@@ -121,6 +121,18 @@ struct SubCells {
 // start and cell_of stay valid: the permutation is within cells).
 int subsort_octants(Ctx* c, DevGrid* g, int64_t n, SubCells* sub);
 
+// The grid AND its octant sub-cells in one go (what DBSCAN bins with): one returning atomic per
+// point (its arrival rank in the cell), one scatter of (index, cell, octant) and one pass that
+// orders every cell's run by octant from the run's own octant bytes (no second counting pass, no
+// per-octant counters), gathers the coordinates and writes every output array once.
+// Extents that would need more than `max_cells` cells of edge `min_cell` are first COMPRESSED
+// per axis: runs of empty slabs collapse to one empty slab, which keeps exactly the adjacencies
+// the 27-cell stencil and the sub-cell offsets use (two points in neighbouring slabs stay in
+// neighbouring slabs, all others end up at least one empty slab apart). Only if the compressed
+// grid is still too large is the edge doubled (g->cell > min_cell tells the caller).
+int build_grid_octants(Ctx* c, const double* xyz, int64_t n, double min_cell, int64_t max_cells,
+                       DevGrid* g, SubCells* sub);
+
 // A grid with cells `factor` times larger over the same points, derived from `fine`
 // by block sums and a deterministic scatter (no atomics, no second pass over xyz).
 int coarsen_grid(Ctx* c, const DevGrid& fine, int64_t n, int factor, DevGrid* coarse);

@@ -153,7 +153,14 @@ __global__ __launch_bounds__(T) void k_knn(int n_query, const int32_t* __restric
 // of a 12*k-byte LDS column per lane. At k = 20 the LDS columns allow two blocks per CU
 // (two waves per SIMD) and the walk is a chain of dependent gathers: occupancy is what it
 // needs. Slots beyond k only make the acceptance test slightly more generous.
-template <int K>
+// BUF > 0: accepted candidates are first pushed into a BUF-slot unsorted per-lane buffer; the
+// sorted insertion (~11 instructions per list slot, executed by the whole wave as soon as ONE
+// lane has a candidate to insert — which at 64 lanes is nearly every candidate) runs only when
+// some lane's buffer is full, for all lanes and all their buffered candidates at once. The
+// acceptance test then works with a slightly stale k-th distance (a superset is buffered);
+// buffers are flushed before every "done" test, so the result is the same list. Measured on the
+// 1 M-point forest, k = 20: see DESIGN.md (k_knn_reg).
+template <int K, int BUF>
 __global__ __launch_bounds__(256) void k_knn_reg(int n_query, KnnGrid g,
                                                  const int32_t* __restrict__ start,
                                                  const int32_t* __restrict__ order,
@@ -179,6 +186,37 @@ __global__ __launch_bounds__(256) void k_knn_reg(int n_query, KnnGrid g,
     bd[j] = __builtin_inf();
     bi[j] = 0x7FFFFFFF;
   }
+  constexpr int NB = BUF > 0 ? BUF : 1;
+  double fd[NB];  // buffered candidates, newest first; empty slots hold (inf, max)
+  int fi[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    fd[j] = __builtin_inf();
+    fi[j] = 0x7FFFFFFF;
+  }
+  int nbuf = 0;
+  // sorted insertion of one candidate; (inf, max) is never smaller than a list entry: a no-op
+  auto insert = [&](double d, int id) {
+    bool lt_cur = d < bd[K - 1] || (d == bd[K - 1] && id < bi[K - 1]);
+#pragma unroll
+    for (int t = K - 1; t > 0; --t) {
+      const bool lt_prev = d < bd[t - 1] || (d == bd[t - 1] && id < bi[t - 1]);
+      bd[t] = lt_prev ? bd[t - 1] : (lt_cur ? d : bd[t]);
+      bi[t] = lt_prev ? bi[t - 1] : (lt_cur ? id : bi[t]);
+      lt_cur = lt_prev;
+    }
+    bd[0] = lt_cur ? d : bd[0];
+    bi[0] = lt_cur ? id : bi[0];
+  };
+  auto flush = [&]() {
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      insert(fd[j], fi[j]);
+      fd[j] = __builtin_inf();
+      fi[j] = 0x7FFFFFFF;
+    }
+    nbuf = 0;
+  };
   bool done = false;
   const int rmax_grid = max(g.nx, max(g.ny, g.nz));
   for (int r = 0; r <= kMaxRing && !done; ++r) {
@@ -204,25 +242,40 @@ __global__ __launch_bounds__(256) void k_knn_reg(int n_query, KnnGrid g,
           if (x0 > x1) continue;
           const int qb = start[row + x0], qe = start[row + x1 + 1];
           for (int q = qb; q < qe; ++q) {
-            if (exclude_self && q == p) continue;
-            const double d = sqdist3(x, y, z, sx[q], sy[q], sz[q]);
-            if (!(d < bd[K - 1] || d == bd[K - 1])) continue;  // cheap reject before the id load
-            const int id = order[q];
-            bool lt_cur = d < bd[K - 1] || (d == bd[K - 1] && id < bi[K - 1]);
-            if (!lt_cur) continue;
+            if constexpr (BUF > 0) {
+              // no early `continue`: every lane that is in this iteration reaches the ballot
+              const double d = sqdist3(x, y, z, sx[q], sy[q], sz[q]);
+              bool acc = !(exclude_self && q == p) && (d < bd[K - 1] || d == bd[K - 1]);
+              int id = 0x7FFFFFFF;
+              if (acc) {
+                id = order[q];
+                acc = d < bd[K - 1] || (d == bd[K - 1] && id < bi[K - 1]);
+              }
+              if (acc) {
 #pragma unroll
-            for (int t = K - 1; t > 0; --t) {
-              const bool lt_prev = d < bd[t - 1] || (d == bd[t - 1] && id < bi[t - 1]);
-              bd[t] = lt_prev ? bd[t - 1] : (lt_cur ? d : bd[t]);
-              bi[t] = lt_prev ? bi[t - 1] : (lt_cur ? id : bi[t]);
-              lt_cur = lt_prev;
+                for (int j = NB - 1; j > 0; --j) {  // push (static indices: registers, not scratch)
+                  fd[j] = fd[j - 1];
+                  fi[j] = fi[j - 1];
+                }
+                fd[0] = d;
+                fi[0] = id;
+                ++nbuf;
+              }
+              // one lane's buffer is full: EVERY lane of the iteration merges what it has
+              if (__ballot(nbuf == NB) != 0ull) flush();
+            } else {
+              if (exclude_self && q == p) continue;
+              const double d = sqdist3(x, y, z, sx[q], sy[q], sz[q]);
+              if (!(d < bd[K - 1] || d == bd[K - 1])) continue;  // cheap reject before the id load
+              const int id = order[q];
+              if (!(d < bd[K - 1] || (d == bd[K - 1] && id < bi[K - 1]))) continue;
+              insert(d, id);
             }
-            bd[0] = lt_cur ? d : bd[0];
-            bi[0] = lt_cur ? id : bi[0];
           }
         }
       }
     }
+    if constexpr (BUF > 0) flush();
     // everything outside the visited cube is at least r cells away
     double kth = __builtin_inf();
 #pragma unroll
@@ -255,13 +308,37 @@ __global__ __launch_bounds__(256) void k_knn_reg(int n_query, KnnGrid g,
     }
 }
 
+static int knn_buffer_slots() {  // PYQSM_KNN_BUF=0: direct insertion (the round-1 kernel)
+  static const int v = [] {
+    const char* e = getenv("PYQSM_KNN_BUF");
+    return e ? atoi(e) : 4;
+  }();
+  return v;
+}
+
 template <int K>
 static int launch_knn_reg(Ctx* c, int n, const DevGrid& g, int k, int excl, int last, int32_t* idx,
                           double* d2, int32_t* fail_list, int32_t* fail_count) {
   KnnGrid kg{g.nx, g.ny, g.nz, g.cell};
-  hipLaunchKernelGGL(k_knn_reg<K>, dim3(ceil_div(n, 256)), dim3(256), 0, c->stream, n, kg, g.start,
-                     g.order, g.cell_of, g.sx, g.sy, g.sz, k, excl, n, last, idx, d2, fail_list,
-                     fail_count);
+  const dim3 grid(ceil_div(n, 256)), blk(256);
+  switch (knn_buffer_slots()) {
+    case 0:
+      hipLaunchKernelGGL((k_knn_reg<K, 0>), grid, blk, 0, c->stream, n, kg, g.start, g.order, g.cell_of, g.sx,
+                         g.sy, g.sz, k, excl, n, last, idx, d2, fail_list, fail_count);
+      break;
+    case 2:
+      hipLaunchKernelGGL((k_knn_reg<K, 2>), grid, blk, 0, c->stream, n, kg, g.start, g.order, g.cell_of, g.sx,
+                         g.sy, g.sz, k, excl, n, last, idx, d2, fail_list, fail_count);
+      break;
+    case 8:
+      hipLaunchKernelGGL((k_knn_reg<K, 8>), grid, blk, 0, c->stream, n, kg, g.start, g.order, g.cell_of, g.sx,
+                         g.sy, g.sz, k, excl, n, last, idx, d2, fail_list, fail_count);
+      break;
+    default:
+      hipLaunchKernelGGL((k_knn_reg<K, 4>), grid, blk, 0, c->stream, n, kg, g.start, g.order, g.cell_of, g.sx,
+                         g.sy, g.sz, k, excl, n, last, idx, d2, fail_list, fail_count);
+  }
+
   PQ_HIP(hipGetLastError());
   return 0;
 }

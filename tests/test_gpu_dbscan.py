@@ -119,16 +119,45 @@ def test_planar_and_single_cell(gpu):
 
 
 def test_extent_far_beyond_the_dense_grid(gpu):
-    """Extent / eps so large that the cell edge is doubled several times to fit the dense grid:
-    cells (and octant sub-cells) are then wider than eps and the sub-cell shortcuts must not
-    be used. Many small clusters inside single cells plus outliers 100 units away."""
+    """Extent / eps far beyond what a dense grid of edge eps can hold (3333^3 cells): the binning
+    drops the empty slabs per axis (grid.hip: build_grid_octants), the cells keep their edge and
+    the sub-cell fast path runs (k_hook_sub is launched). Many small clusters inside single
+    cells plus outliers 100 units away."""
     rng = np.random.default_rng(11)
     blob = rng.uniform(0, 0.6, (6000, 3))
     far = rng.uniform(-50, 50, (40, 3))
     P = np.concatenate([blob, far]).astype(np.float32).astype(np.float64)
+    hip.prof_enable(True, gpu)
+    hip.prof_reset(gpu)
     lab, core = _check(P, 0.03, 4, gpu)
+    launches = hip.prof_get("k_hook_sub", gpu)[1]
+    hip.prof_enable(False, gpu)
+    assert launches >= 1                                  # the sub-cell path, not k_union_points
     assert lab.max() > 5 and (lab == -1).sum() > 40 and (~core & (lab >= 0)).sum() > 0
     _check(P, 0.012, 1, gpu)
+
+
+def test_two_dense_blobs_a_kilometre_apart(gpu):
+    """Compression has to keep neighbours neighbours: clusters that straddle slab boundaries
+    next to long empty stretches, on every axis."""
+    rng = np.random.default_rng(12)
+    a = rng.uniform(0, 0.5, (4000, 3))
+    b = rng.uniform(0, 0.5, (4000, 3)) + [1000.0, -750.0, 300.0]
+    chain = np.stack([np.linspace(0, 3, 400), np.zeros(400), np.zeros(400)], 1) + [500.0, 0, 0]
+    P = np.concatenate([a, b, chain, rng.uniform(-1000, 1000, (30, 3))])
+    P = P.astype(np.float32).astype(np.float64)
+    _check(P, 0.04, 5, gpu)
+    _check(P, 0.011, 2, gpu)
+
+
+def test_cells_with_hundreds_of_points(gpu):
+    """eps far above the point spacing: cells hold more than kBigCell points and are ordered by
+    the block-per-cell pass; also everything in ONE cell."""
+    rng = np.random.default_rng(13)
+    P = rng.uniform(0, 1, (30_000, 3)).astype(np.float32).astype(np.float64)
+    _check(P, 0.2, 10, gpu)
+    _check(P * [1, 1, 0.01], 0.25, 50, gpu)
+    _check(rng.uniform(0, 0.01, (3000, 3)), 1.0, 5, gpu)
 
 
 def test_randomised_differential(gpu):

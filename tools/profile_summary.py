@@ -1,41 +1,106 @@
-"""dev aid: condense rocprofv3 outputs under gpurun_out/ into the summaries kept in profiles/."""
-import csv, json, collections, sys
-ROUND = "r01"
-out = "profiles"
-# 1. kernel stats of the bench command
-rows = list(csv.DictReader(open("gpurun_out/prof_final/bench_kernel_stats.csv")))
-with open(f"{out}/{ROUND}_bench_kernel_stats_final.csv", "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py  (round 1, end of round; under the\n")
-    f.write("# profiler the multigrid iterations are launched kernel by kernel instead of replayed as hipGraphs: lbc.hip graphs_enabled())\n")
+"""dev aid: condense the rocprofv3 outputs of tools/profile_r02.sh (gpurun_out/prof_r02/) into the
+summaries kept under profiles/ (tracked)."""
+import collections
+import csv
+import glob
+import json
+import os
+
+ROUND = "r02"
+SRC = "gpurun_out/prof_r02"
+OUT = "profiles"
+
+
+def find(sub, suffix):
+    hits = sorted(glob.glob(f"{SRC}/{sub}/**/*{suffix}", recursive=True))
+    if not hits:
+        raise SystemExit(f"no {suffix} under {SRC}/{sub}")
+    return hits[-1]
+
+
+def short(name):
+    return name.split("(")[0].replace("void ", "")
+
+
+# 1. kernel stats of the whole default bench run
+rows = list(csv.DictReader(open(find("bench", "kernel_stats.csv"))))
+with open(f"{OUT}/{ROUND}_bench_kernel_stats.csv", "w") as f:
+    f.write("# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu  (round 2;\n")
+    f.write("# hipGraph replays are ON under the profiler: the library no longer looks at ROCP_TOOL_LIBRARIES)\n")
     f.write("kernel,calls,avg_us,total_ms,percent\n")
     for r in rows:
-        f.write('"%s",%s,%.2f,%.3f,%s\n' % (r["Name"].split("(")[0], r["Calls"], float(r["AverageNs"]) / 1e3,
-                                           float(r["TotalDurationNs"]) / 1e6, r["Percentage"]))
-# 2. PMC passes
-def pmc(path, counter):
-    acc = collections.defaultdict(list)
-    for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] == counter:
-            acc[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+        f.write('"%s",%s,%.2f,%.3f,%s\n' % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e3,
+                                              float(r["TotalDurationNs"]) / 1e6, r["Percentage"]))
+bj = open(f"{SRC}/bench.json").read().strip().splitlines()[-1]
+open(f"{OUT}/{ROUND}_bench_under_rocprof.json", "w").write(bj + "\n")
+
+
+def pmc(sub, counters):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(find(sub, "counter_collection.csv"))):
+        if r["Counter_Name"] in counters:
+            acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return acc
-fetch = pmc("gpurun_out/prof_fetch/f_counter_collection.csv", "FETCH_SIZE")
-write = pmc("gpurun_out/prof_write/w_counter_collection.csv", "WRITE_SIZE")
+
+
+# 2. HBM traffic of the DBSCAN kernels
 cmd = "python3 bench.py --steps 3 --warmup 1 --no-rays --no-knn --no-skeleton --no-ransac --no-cpu"
+fetch, write = pmc("fetch", {"FETCH_SIZE"}), pmc("write", {"WRITE_SIZE"})
 for name, acc, cname in (("fetch_size", fetch, "FETCH_SIZE"), ("write_size", write, "WRITE_SIZE")):
-    with open(f"{out}/{ROUND}_dbscan_pmc_{name}_final.csv", "w") as f:
-        f.write(f"# rocprofv3 --kernel-trace --pmc {cname} -- {cmd}  (round 1, end of round)\n")
+    with open(f"{OUT}/{ROUND}_dbscan_pmc_{name}.csv", "w") as f:
+        f.write(f"# rocprofv3 --kernel-trace --pmc {cname} -- {cmd}  (round 2)\n")
         f.write("# counter unit: KiB as reported by rocprofv3; gfx950 FETCH_SIZE reports half the bytes of wide (16 B/lane)\n")
         f.write("# coalesced streaming reads (MI355X_MICROARCH.md, HBM section); these kernels read 4-8 B per lane: uncalibrated\n")
         f.write("kernel,dispatches,avg_counter_value_kib\n")
-        for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
-            f.write('"%s",%d,%.2f\n' % (k, len(v), sum(v) / len(v)))
+        for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1][cname])):
+            f.write('"%s",%d,%.2f\n' % (k, len(v[cname]), sum(v[cname]) / len(v[cname])))
 kern = {}
-for scope, k in (("k_core_tiled", "pyqsm::k_core_tiled"), ("k_hook_sub", "pyqsm::k_hook_sub"), ("k_union_sub", "pyqsm::k_union_sub")):
-    fk = sum(fetch[k]) / len(fetch[k]); wk = sum(write[k]) / len(write[k])
-    kern[scope] = {"fetch_size_kib": fk, "write_size_kib": wk, "hbm_bytes_per_launch": (fk + wk) * 1024.0}
+for k in fetch:
+    if k in write and k.startswith("pyqsm::k_"):
+        fk = sum(fetch[k]["FETCH_SIZE"]) / len(fetch[k]["FETCH_SIZE"])
+        wk = sum(write[k]["WRITE_SIZE"]) / len(write[k]["WRITE_SIZE"])
+        kern[k.replace("pyqsm::", "")] = {"fetch_size_kib": fk, "write_size_kib": wk,
+                                          "hbm_bytes_per_launch": (fk + wk) * 1024.0}
 json.dump({"points": 1_000_000, "kernels": kern,
-           "note": "FETCH_SIZE + WRITE_SIZE per launch from separate rocprofv3 --pmc passes (profiles/r01_dbscan_pmc_*_final.csv), "
-                   "raw counter x 1024 B; the gfx950 2x correction of FETCH_SIZE is calibrated for 16 B/lane streaming reads only "
-                   "and is NOT applied (these kernels read 4-8 B per lane), so the figure is a lower bound of the read traffic"},
-          open(f"{out}/{ROUND}_dbscan_traffic.json", "w"), indent=1)
+           "note": "FETCH_SIZE + WRITE_SIZE per launch from separate rocprofv3 --pmc passes "
+                   f"(profiles/{ROUND}_dbscan_pmc_*.csv), raw counter x 1024 B; the gfx950 2x correction of FETCH_SIZE "
+                   "is calibrated for 16 B/lane streaming reads only and is NOT applied (these kernels read 4-8 B per "
+                   "lane), so the figure is a lower bound of the read traffic"},
+          open(f"{OUT}/{ROUND}_dbscan_traffic.json", "w"), indent=1)
+
+
+# 3. SQ counter passes
+def sq(sub, out_name, cmdline, keep):
+    path = find(sub, "counter_collection.csv")
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    names = []
+    for r in csv.DictReader(open(path)):
+        acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if r["Counter_Name"] not in names:
+            names.append(r["Counter_Name"])
+    names.sort()
+    with open(f"{OUT}/{ROUND}_{out_name}.csv", "w") as f:
+        f.write(f"# rocprofv3 --kernel-trace --pmc {' '.join(names)} -- {cmdline}  (round 2)\n")
+        f.write("# per-dispatch averages; SQ_*_CYCLES and SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over "
+                "waves (MI355X_MICROARCH.md)\n")
+        f.write("kernel,dispatches," + ",".join(names) + "\n")
+        for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1].get("SQ_WAVE_CYCLES", [0]))):
+            if keep and not any(s in k for s in keep):
+                continue
+            n = max(len(x) for x in v.values())
+            f.write('"%s",%d,' % (k, n) + ",".join("%.0f" % (sum(v[c]) / len(v[c])) if v.get(c) else "" for c in names) + "\n")
+
+
+sq("sq_dbscan", "dbscan_sq_counters", cmd, None)
+sq("sq_rays", "rays_sq_counters",
+   "python3 bench.py --steps 2 --warmup 1 --no-knn --no-skeleton --no-ransac --no-cpu --ray-steps 1", ["k_cast", "k_dir"])
+sq("sq_knn", "knn_sq_counters",
+   "python3 bench.py --steps 2 --warmup 1 --no-rays --no-skeleton --no-ransac --no-cpu", ["k_knn"])
+# 4. graphs under the profiler
+log = open(f"{SRC}/graph_jacobi.log").read()
+open(f"{OUT}/{ROUND}_graph_under_rocprof.txt", "w").write(
+    "# rocprofv3 --kernel-trace --stats -- python3 tools/graph_under_rocprof.py jacobi  (round 2): the Jacobi-PCG bursts\n"
+    "# replayed as hipGraphs under the profiler; round 1 reported a crash here and switched graphs off when\n"
+    "# ROCP_TOOL_LIBRARIES was set. Not reproducible: both graph paths (also PYQSM_AMG_GRAPH=1) run to completion.\n"
+    + "\n".join(l for l in log.splitlines() if "solve returned" in l or "laplacian built" in l) + "\n")
 print(json.dumps(kern, indent=1))
