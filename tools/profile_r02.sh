@@ -1,14 +1,14 @@
 #!/bin/bash
 # Round-2 profiles on the GPU box (run through gpurun from the repo root):
 #   bash tools/profile_r02.sh
-# Writes raw rocprofv3 output under gpurun_out/prof_r02/; tools/profile_summary.py condenses it into
-# profiles/r02_*. The program goes directly after `--` (no env/bash hop under rocprofv3). PMC passes
+# Raw rocprofv3 output goes to /tmp on the box; tools/profile_summary.py condenses it into
+# gpurun_out/prof_r02_summary/r02_* (copy those into profiles/). The program goes directly after `--` (no env/bash hop under rocprofv3). PMC passes
 # carry only --kernel-trace. hipGraph replays stay ON under the profiler (the round-1 workaround that
 # sniffed ROCP_TOOL_LIBRARIES is gone; tools/graph_under_rocprof.py is the regression check).
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/prof_r02
-mkdir -p $O
+O=/tmp/prof_r02          # raw traces are large: they stay on the box
+rm -rf $O; mkdir -p $O
 DB="--steps 3 --warmup 1 --no-rays --no-knn --no-skeleton --no-ransac --no-cpu"
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench -o bench -- python3 $R/bench.py --no-cpu > $O/bench.json 2> $O/bench.err
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -o f -- python3 $R/bench.py $DB > $O/fetch.json 2> $O/fetch.err
@@ -20,4 +20,8 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VA
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVES SQ_ACTIVE_INST_ANY --output-format csv -d $O/sq_knn -o s -- python3 $R/bench.py --steps 2 --warmup 1 --no-rays --no-skeleton --no-ransac --no-cpu > $O/sq_knn.json 2> $O/sq_knn.err
 # both hipGraph paths of the solver under the profiler
 timeout -k 10 120 rocprofv3 --kernel-trace --stats --output-format csv -d $O/graph_jacobi -o g -- python3 $R/tools/graph_under_rocprof.py jacobi > $O/graph_jacobi.log 2>&1
-ls $O/*/* | head -40
+cd $R
+mkdir -p gpurun_out/prof_r02_summary
+python3 tools/profile_summary.py $O gpurun_out/prof_r02_summary > gpurun_out/prof_r02_summary/summary.log 2>&1
+for f in $O/*.err; do echo "== $f"; tail -3 $f; done > gpurun_out/prof_r02_summary/stderr_tails.log 2>&1
+tail -5 gpurun_out/prof_r02_summary/summary.log

@@ -6,9 +6,12 @@ import glob
 import json
 import os
 
+import sys
+
 ROUND = "r02"
-SRC = "gpurun_out/prof_r02"
-OUT = "profiles"
+SRC = sys.argv[1] if len(sys.argv) > 1 else "/tmp/prof_r02"
+OUT = sys.argv[2] if len(sys.argv) > 2 else "profiles"
+os.makedirs(OUT, exist_ok=True)
 
 
 def find(sub, suffix):
