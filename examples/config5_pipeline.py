@@ -24,7 +24,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pyqsm_amd import _lib, synth  # noqa: E402
-from pyqsm_amd.geometry.skeletonize import extract_skeleton  # noqa: E402
+from pyqsm_amd.geometry.skeletonize import extract_skeleton, extract_skeleton_batch  # noqa: E402
 from pyqsm_amd.math_utils.fit import cluster_DBSCAN, draw_samples, fit_shape_RANSAC  # noqa: E402
 from pyqsm_amd.set_config import config  # noqa: E402
 from pyqsm_amd.viz.ray_casting import cast_rays  # noqa: E402
@@ -39,6 +39,9 @@ def main():
                     help="host threads PER GPU that contract trees concurrently (the library keeps "
                          "one stream and arena per thread; a 50 k-point tree alone is latency-bound)")
     ap.add_argument("--gpus", type=int, default=1, help="GPUs of this node to use (0 = all visible)")
+    ap.add_argument("--group-points", type=int, default=600_000,
+                    help="trees are contracted in block-diagonal groups of up to this many points "
+                         "(extract_skeleton_batch); 0 = one extract_skeleton call per tree")
     args = ap.parse_args()
     n_gpus = args.gpus if args.gpus > 0 else _lib.device_count()
     if n_gpus > _lib.device_count():
@@ -65,8 +68,21 @@ def main():
                                                           termination_ratio=0.0, device=k % n_gpus)
         return float(np.linalg.norm(total_shift, axis=1).mean())
 
-    with ThreadPoolExecutor(max_workers=max(1, args.workers) * n_gpus) as pool:
-        shifts = list(pool.map(contract, enumerate(idxs[: args.max_trees])))
+    trees = idxs[: args.max_trees]
+    if args.group_points > 0:
+        # GPU d takes every n_gpus-th tree and contracts its share in block-diagonal groups
+        def contract_share(d):
+            share = [pts[t] for t in trees[d::n_gpus]]
+            res = extract_skeleton_batch(share, max_iter=args.skeleton_iters, termination_ratio=0.0,
+                                         device=d, group_points=args.group_points,
+                                         workers=max(1, min(args.workers, 4)))
+            return [float(np.linalg.norm(r[1], axis=1).mean()) for r in res]
+
+        with ThreadPoolExecutor(max_workers=n_gpus) as pool:
+            shifts = [s for part in pool.map(contract_share, range(n_gpus)) for s in part]
+    else:
+        with ThreadPoolExecutor(max_workers=max(1, args.workers) * n_gpus) as pool:
+            shifts = list(pool.map(contract, enumerate(trees)))
     out["skeleton_s"] = time.perf_counter() - t0
     out["skeleton_trees"] = len(shifts)
     out["skeleton_workers"] = max(1, args.workers)

@@ -312,6 +312,18 @@ int pyqsm_fps(const double* xyz, int64_t n, int64_t num_samples, int64_t start_i
 int pyqsm_pc_laplacian(const double* xyz, int64_t n, int32_t k, double moll,
                        int64_t* nnz, int32_t** indptr, int32_t** indices, double** vals,
                        double* mass, int32_t device);
+/*
+ * The same for several clouds stacked into one array (the per-cluster calls of
+ * pyQSM/qsm_generation.py:182-316 batched into one build): points [seg_start[s],
+ * seg_start[s+1]) are cloud s, n_seg clouds, seg_start i64 [n_seg + 1] from 0 to n.
+ * The mollification length (max(0, largest triangle slack + moll x mean edge length))
+ * is taken per cloud, as n_seg separate calls would. The clouds must lie apart (further
+ * than any k-neighbourhood reaches) for the result to be block diagonal; the caller
+ * arranges that (extract_skeleton_batch moves every cloud to its own lattice cell).
+ */
+int pyqsm_pc_laplacian_seg(const double* xyz, int64_t n, const int64_t* seg_start, int64_t n_seg,
+                           int32_t k, double moll, int64_t* nnz, int32_t** indptr,
+                           int32_t** indices, double** vals, double* mass, int32_t device);
 
 #ifdef __cplusplus
 }

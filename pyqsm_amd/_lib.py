@@ -67,6 +67,9 @@ SIGNATURES = {
     "pyqsm_pc_laplacian": (ctypes.c_int, [vp, i64, i32, dbl, ctypes.POINTER(i64),
                                           ctypes.POINTER(vp), ctypes.POINTER(vp),
                                           ctypes.POINTER(vp), vp, i32]),
+    "pyqsm_pc_laplacian_seg": (ctypes.c_int, [vp, i64, vp, i64, i32, dbl, ctypes.POINTER(i64),
+                                              ctypes.POINTER(vp), ctypes.POINTER(vp),
+                                              ctypes.POINTER(vp), vp, i32]),
 }
 
 _lib = None

@@ -334,15 +334,73 @@ static constexpr int kFlipBatch = 8;  // rounds queued between two looks at the 
 __device__ __host__ inline int nx3(int c) { return c == 2 ? 0 : c + 1; }
 __device__ __host__ inline int pv3(int c) { return c == 0 ? 2 : c - 1; }
 
+// Several clouds in one build (extract_skeleton_batch): the mollification length is a property
+// of each cloud — max(0, its largest triangle-inequality slack + moll x its mean edge length) — so
+// it is reduced per SEGMENT of points. Triangles are stored fan by fan in point order, so the
+// triangles of segment s are the range [tstart[s], tstart[s+1]) with tstart = tcount[seg_start].
+// One block per segment, fixed reduction tree (deterministic).
+__global__ __launch_bounds__(256) void k_seg_eps(int S, const int32_t* __restrict__ seg_start,
+                                                 const int32_t* __restrict__ tcount /*scanned*/,
+                                                 const double* __restrict__ len, double moll,
+                                                 int32_t* __restrict__ tstart /*[S + 1]*/,
+                                                 double* __restrict__ eps_out /*[S]*/) {
+  __shared__ double s_sum[256], s_slk[256];
+  const int sidx = blockIdx.x;
+  const int tb = tcount[seg_start[sidx]], te = tcount[seg_start[sidx + 1]];
+  double sum = 0.0, slack = -__builtin_inf();
+  for (int t = tb + threadIdx.x; t < te; t += 256) {
+    const double la = len[3 * size_t(t)], lb = len[3 * size_t(t) + 1], lc = len[3 * size_t(t) + 2];
+    sum += (la + lb) + lc;
+    const double s0 = la - lb - lc, s1 = lb - la - lc, s2 = lc - la - lb;
+    double m = s0 > s1 ? s0 : s1;
+    m = s2 > m ? s2 : m;
+    slack = m > slack ? m : slack;
+  }
+  s_sum[threadIdx.x] = sum;
+  s_slk[threadIdx.x] = slack;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) {
+      s_sum[threadIdx.x] += s_sum[threadIdx.x + off];
+      const double o = s_slk[threadIdx.x + off];
+      if (o > s_slk[threadIdx.x]) s_slk[threadIdx.x] = o;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const int Ts = te - tb;
+    const double mean = Ts > 0 ? s_sum[0] / (3.0 * double(Ts)) : 0.0;
+    const double e = s_slk[0] + mean * moll;
+    eps_out[sidx] = (Ts > 0 && e > 0.0) ? e : 0.0;
+    tstart[sidx] = tb;
+    if (sidx == S - 1) tstart[S] = te;
+  }
+}
+
+// eps of every triangle (its segment found by bisection over tstart): the array k_cover_init reads
+__global__ __launch_bounds__(256) void k_tri_eps(int T, int S, const int32_t* __restrict__ tstart,
+                                                 const double* __restrict__ eps_seg,
+                                                 double* __restrict__ eps_tri) {
+  int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= T) return;
+  int lo = 0, hi = S;  // largest s with tstart[s] <= t
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (tstart[mid] <= t) lo = mid; else hi = mid;
+  }
+  eps_tri[t] = eps_seg[lo];
+}
+
 __global__ __launch_bounds__(256) void k_cover_init(int T, const int32_t* __restrict__ tris,
                                                     const double* __restrict__ len,
                                                     const double* __restrict__ eps_p,
+                                                    const double* __restrict__ eps_tri /*null: eps_p[0]*/,
                                                     int32_t* __restrict__ fv,
                                                     double* __restrict__ fl,
                                                     int32_t* __restrict__ bcount) {
   int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= T) return;
-  const double eps = eps_p[0];
+  const double eps = eps_tri ? eps_tri[t] : eps_p[0];
   const int v0 = tris[3 * size_t(t)], v1 = tris[3 * size_t(t) + 1], v2 = tris[3 * size_t(t) + 2];
   // len[] holds the side opposite vertex 0, 1, 2
   const double la = len[3 * size_t(t)] + eps, lb = len[3 * size_t(t) + 1] + eps,
@@ -829,11 +887,16 @@ using namespace pyqsm;
 
 extern "C" {
 
-int pyqsm_pc_laplacian(const double* xyz, int64_t n, int32_t k, double moll, int64_t* nnz_out,
-                       int32_t** indptr_out, int32_t** indices_out, double** vals_out,
-                       double* mass, int32_t device) {
-  PQ_API_RANGE("pyqsm_pc_laplacian");
+static int pc_laplacian_impl(const double* xyz, int64_t n, const int64_t* seg_start, int64_t n_seg,
+                             int32_t k, double moll, int64_t* nnz_out, int32_t** indptr_out,
+                             int32_t** indices_out, double** vals_out, double* mass, int32_t device) {
   if (n < 0) return fail(PYQSM_EINVAL, "negative size");
+  if (n_seg > 1) {
+    if (!seg_start) return fail(PYQSM_EINVAL, "pyqsm_pc_laplacian_seg: NULL seg_start");
+    if (seg_start[0] != 0 || seg_start[n_seg] != n) return fail(PYQSM_EINVAL, "seg_start must run from 0 to n");
+    for (int64_t q = 0; q < n_seg; ++q)
+      if (seg_start[q + 1] < seg_start[q]) return fail(PYQSM_EINVAL, "seg_start must be non-decreasing");
+  }
   if (!nnz_out || !indptr_out || !indices_out || !vals_out)
     return fail(PYQSM_EINVAL, "pyqsm_pc_laplacian: NULL out-parameter");
   *nnz_out = 0;
@@ -936,9 +999,27 @@ int pyqsm_pc_laplacian(const double* xyz, int64_t n, int32_t k, double moll, int
     }
     hipLaunchKernelGGL(k_mollify_eps, dim3(1), dim3(64), 0, c->stream, T > 0 ? nblk : 0, T,
                        d_blk_sum, d_blk_slack, moll, d_eps);
+    double* d_eps_tri = nullptr;
+    if (T > 0 && n_seg > 1) {  // one mollification length per cloud of the batch
+      int32_t *d_seg_start, *d_tstart;
+      double* d_eps_seg;
+      PQ_TRY(c->arena.get(size_t(n_seg) + 1, &d_seg_start));
+      PQ_TRY(c->arena.get(size_t(n_seg) + 1, &d_tstart));
+      PQ_TRY(c->arena.get(size_t(n_seg), &d_eps_seg));
+      PQ_TRY(c->arena.get(size_t(T), &d_eps_tri));
+      std::vector<int32_t> h32(size_t(n_seg) + 1);
+      for (int64_t q = 0; q <= n_seg; ++q) h32[size_t(q)] = int32_t(seg_start[q]);
+      PQ_HIP(hipMemcpyAsync(d_seg_start, h32.data(), (size_t(n_seg) + 1) * 4, hipMemcpyHostToDevice,
+                            c->stream));
+      hipLaunchKernelGGL(k_seg_eps, dim3(unsigned(n_seg)), blk, 0, c->stream, int(n_seg), d_seg_start, d_tcount,
+                         d_len, moll, d_tstart, d_eps_seg);
+      hipLaunchKernelGGL(k_tri_eps, gt, blk, 0, c->stream, T, int(n_seg), d_tstart, d_eps_seg, d_eps_tri);
+      PQ_HIP(hipGetLastError());
+      PQ_HIP(hipStreamSynchronize(c->stream));  // h32 goes out of scope
+    }
     if (T > 0) {
       // tufted cover: two faces per triangle, glued around every edge
-      hipLaunchKernelGGL(k_cover_init, gt, blk, 0, c->stream, T, d_tris, d_len, d_eps, d_fv, d_fl,
+      hipLaunchKernelGGL(k_cover_init, gt, blk, 0, c->stream, T, d_tris, d_len, d_eps, d_eps_tri, d_fv, d_fl,
                          d_bcount);
       PQ_TRY(exclusive_scan_i32(c, d_bcount, n + 1));
       hipLaunchKernelGGL(k_edge_scatter, gt, blk, 0, c->stream, T, d_tris, d_bcount, d_bcursor,
@@ -1054,6 +1135,23 @@ int pyqsm_pc_laplacian(const double* xyz, int64_t n, int32_t k, double moll, int
   }
   *indptr_out = h_indptr;
   return 0;
+}
+
+int pyqsm_pc_laplacian(const double* xyz, int64_t n, int32_t k, double moll, int64_t* nnz_out,
+                       int32_t** indptr_out, int32_t** indices_out, double** vals_out,
+                       double* mass, int32_t device) {
+  PQ_API_RANGE("pyqsm_pc_laplacian");
+  return pc_laplacian_impl(xyz, n, nullptr, 1, k, moll, nnz_out, indptr_out, indices_out, vals_out, mass,
+                           device);
+}
+
+int pyqsm_pc_laplacian_seg(const double* xyz, int64_t n, const int64_t* seg_start, int64_t n_seg,
+                           int32_t k, double moll, int64_t* nnz_out, int32_t** indptr_out,
+                           int32_t** indices_out, double** vals_out, double* mass, int32_t device) {
+  PQ_API_RANGE("pyqsm_pc_laplacian_seg");
+  if (n_seg < 1) return fail(PYQSM_EINVAL, "n_seg must be >= 1");
+  return pc_laplacian_impl(xyz, n, seg_start, n_seg, k, moll, nnz_out, indptr_out, indices_out, vals_out,
+                           mass, device);
 }
 
 }  // extern "C"

@@ -35,14 +35,14 @@ SOLVER_RTOL = 1e-8       # relative error estimate |B^-2 r| / |x| at which the s
 SOLVER_MAX_IT = 5_000_000   # cap on the total number of inner CG iterations
 
 
-def point_cloud_laplacian(pts, mollify_factor=1e-5, n_neighbors=30, device: int = 0):
+def point_cloud_laplacian(pts, mollify_factor=1e-5, n_neighbors=30, device: int = 0, seg_start=None):
     """``(L, M)`` like ``robust_laplacian.point_cloud_laplacian``: L a SciPy CSR
     matrix (weak Laplacian, symmetric, zero row sums), M a diagonal SciPy matrix
     (lumped mass), so that ``M.diagonal()`` works as at skeletonize.py:259."""
     from scipy.sparse import csr_matrix, diags
     pts = as_points(pts)
     (indptr, indices, data), mass = hip.pc_laplacian(pts, n_neighbors, mollify_factor,
-                                                     device=device)
+                                                     device=device, seg_start=seg_start)
     n = len(pts)
     L = csr_matrix((data, indices, indptr), shape=(n, n))
     L.has_sorted_indices = True          # rows are written in column order (laplacian.hip: k_rows)
@@ -235,6 +235,137 @@ def extract_skeleton(pcd, moll=_SK["moll"], n_neighbors=_SK["n_neighbors"],
 
 
 skeletonize = extract_skeleton   # BASELINE.json north_star name
+
+
+def _pack_groups(sizes, group_points):
+    """Greedy packing of cloud indices (largest first) into groups of at most ``group_points``
+    points (a cloud larger than that gets a group of its own)."""
+    groups, loads = [], []
+    for j in sorted(range(len(sizes)), key=lambda q: -sizes[q]):
+        for g in range(len(groups)):
+            if loads[g] + sizes[j] <= group_points:
+                groups[g].append(j)
+                loads[g] += sizes[j]
+                break
+        else:
+            groups.append([j])
+            loads.append(sizes[j])
+    return groups
+
+
+def _contract_group(clouds, moll, n_neighbors, max_iter, termination_ratio, contraction_factor,
+                    attraction_factor, max_contraction, max_attraction, device):
+    """extract_skeleton's loop (skeletonize.py:240-373) for SEVERAL clouds at once: they are laid
+    out side by side (every cloud moved to its own cell of a coarse lattice, far from the
+    others), so that ONE Laplacian build and ONE contraction solve per step serve them all — the
+    Laplacian of the union is block diagonal, one block per cloud — while every piece of the
+    loop's bookkeeping (initial weight from the cloud's own mean mass :265, W_H update from its
+    own masses :331, clamp into its own oriented bounds :291-296, volume ratio and termination
+    :279,349,353) stays per cloud. A 50 k-point tree alone is a chain of ~25 dependent 3-us
+    kernels per multigrid-CG iteration; eight of them in one system cost little more per
+    iteration than one."""
+    S = len(clouds)
+    pts = [np.array(as_points(c), dtype=np.float64) for c in clouds]
+    sizes = np.array([len(p) for p in pts])
+    seg = np.repeat(np.arange(S), sizes)
+    start = np.concatenate([[0], np.cumsum(sizes)])
+    # lattice pitch: the largest extent plus a margin; translation changes fp64 results only by
+    # the rounding of the shifted coordinates (~1e-16 x pitch / point spacing)
+    ext = max(float((p.max(0) - p.min(0)).max()) for p in pts)
+    pitch = 2.0 * ext + 1.0
+    cols = int(np.ceil(np.sqrt(S)))
+    offs = np.array([[(j % cols) * pitch, (j // cols) * pitch, 0.0] for j in range(S)])
+    offs -= np.array([0.5 * (p.max(0) + p.min(0)) for p in pts])
+    bounds = [oriented_bounds(p) for p in pts]                          # :240-241, per cloud
+    lo = np.concatenate([np.tile(b[0] + o, (n, 1)) for b, o, n in zip(bounds, offs, sizes)])
+    hi = np.concatenate([np.tile(b[1] + o, (n, 1)) for b, o, n in zip(bounds, offs, sizes)])
+    cur = np.concatenate([p + o for p, o in zip(pts, offs)])
+
+    def seg_mean(v):
+        return np.add.reduceat(v, start[:-1]) / sizes
+
+    L, M = point_cloud_laplacian(cur, mollify_factor=moll, n_neighbors=n_neighbors, device=device,
+                                 seg_start=start)
+    m_used = M.diagonal()
+    m0 = m_used.copy()
+    mean0 = seg_mean(m0)
+    wh = attraction_factor * np.ones(len(cur))                          # :264
+    wl_seg = contraction_factor * 10 ** 3 * np.sqrt(mean0)              # :265, per cloud
+    active = np.ones(S, dtype=bool)
+    iteration = np.zeros(S, dtype=np.int64)
+    volume_ratio = np.ones(S)
+    total = np.zeros_like(cur)
+    steps = [[] for _ in range(S)]
+    solve_log = [[] for _ in range(S)]
+    while active.any():
+        active &= volume_ratio > termination_ratio                      # :279
+        if not active.any():
+            break
+        info = []
+        new = least_squares_sparse(cur, L, wl_seg[seg], wh, device=device, info=info)
+        same = np.array([(new[start[j]:start[j + 1]] == cur[start[j]:start[j + 1]]).all()
+                         for j in range(S)])
+        active &= ~same                                                 # :287-289
+        act_pt = active[seg]
+        new = np.where(act_pt[:, None], np.minimum(np.maximum(new, lo), hi), cur)   # :291-296
+        shift = cur - new
+        total += shift
+        cur = new
+        for j in np.flatnonzero(active):
+            steps[j].append(shift[start[j]:start[j + 1]].copy())
+            solve_log[j].append(dict(info[0]))
+        wl_seg = np.where(active, np.clip(wl_seg * contraction_factor, 0.1, max_contraction), wl_seg)
+        wh = np.where(act_pt, np.clip(wh * np.sqrt(m0 / m_used), 0.1, max_attraction), wh)   # :331-335
+        mean_used = seg_mean(m_used)                                    # M_list[-1] of :337,349
+        iteration += active
+        L, M = point_cloud_laplacian(cur, mollify_factor=moll, n_neighbors=n_neighbors, device=device,
+                                     seg_start=start)
+        m_used = M.diagonal()
+        volume_ratio = np.where(active, mean_used / mean0, volume_ratio)
+        active &= iteration < max_iter                                  # :353-360
+    out = []
+    for j in range(S):
+        a, b = start[j], start[j + 1]
+        pc = PointCloud(cur[a:b] - offs[j])
+        pc.solve_log = solve_log[j]
+        out.append((pc, total[a:b].copy(), steps[j]))
+    return out
+
+
+def extract_skeleton_batch(pcds, moll=_SK["moll"], n_neighbors=_SK["n_neighbors"],
+                           max_iter=_SK["max_iter"], termination_ratio=_SK["termination_ratio"],
+                           contraction_factor=_SK["init_contraction"],
+                           attraction_factor=_SK["init_attraction"],
+                           max_contraction=_SK["max_contraction"],
+                           max_attraction=_SK["max_attraction"], device: int = 0,
+                           group_points: int = 400_000, workers: int = 4):
+    """``extract_skeleton`` for MANY clouds (the per-cluster calls of qsm_generation.py:182-316):
+    returns one ``(contracted, total_point_shift, shift_by_step)`` triple per input cloud, in
+    input order. Clouds are packed into groups of up to ``group_points`` points; a group is
+    contracted as ONE block-diagonal system per step (:func:`_contract_group`) and ``workers``
+    host threads contract groups concurrently (the library keeps a stream per thread).
+
+    Every cloud keeps its own weights, bounds, termination and mollification length
+    (``pyqsm_pc_laplacian_seg``); what the clouds of a group share is the CG scalars of the
+    solve, so results agree with the per-cloud loop to the solver's tolerance
+    (tests/test_gpu_batch.py), not bit for bit."""
+    from concurrent.futures import ThreadPoolExecutor
+    clouds = list(pcds)
+    sizes = [len(as_points(c)) for c in clouds]
+    groups = _pack_groups(sizes, int(group_points))
+    args = (moll, n_neighbors, max_iter, termination_ratio, contraction_factor, attraction_factor,
+            max_contraction, max_attraction, device)
+
+    def run(g):
+        return g, _contract_group([clouds[j] for j in g], *args)
+
+    results = [None] * len(clouds)
+    with ThreadPoolExecutor(max_workers=max(1, int(workers))) as pool:
+        for g, res in pool.map(run, groups):
+            for j, r in zip(g, res):
+                results[j] = r
+    return results
+
 
 
 # --------------------------------------------------------------------------------------

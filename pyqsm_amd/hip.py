@@ -415,17 +415,25 @@ def _adopt(lib, ptr, ctype, count: int, dtype):
     return np.frombuffer(buf, dtype=dtype, count=count)
 
 
-def pc_laplacian(points, k: int = 30, moll: float = 1e-5, device: int = 0):
-    """(indptr, indices, data) CSR triple and lumped mass [n]."""
+def pc_laplacian(points, k: int = 30, moll: float = 1e-5, device: int = 0, seg_start=None):
+    """(indptr, indices, data) CSR triple and lumped mass [n]. ``seg_start`` (int64 [S+1], from 0
+    to n): the points are S clouds stacked into one array and the mollification length is taken
+    per cloud (``pyqsm_pc_laplacian_seg``)."""
     pts = _points(points)
     n = pts.shape[0]
     lib = _lib.load()
     nnz = i64(0)
     ip, ix, dv = vp(), vp(), vp()
     mass = np.empty(n, dtype=np.float64)
-    check(lib.pyqsm_pc_laplacian(_p(pts), n, int(k), float(moll), ctypes.byref(nnz),
-                                 ctypes.byref(ip), ctypes.byref(ix), ctypes.byref(dv), _p(mass),
-                                 int(device)))
+    if seg_start is not None and len(seg_start) > 2:
+        ss = np.ascontiguousarray(seg_start, dtype=np.int64)
+        check(lib.pyqsm_pc_laplacian_seg(_p(pts), n, _p(ss), len(ss) - 1, int(k), float(moll),
+                                         ctypes.byref(nnz), ctypes.byref(ip), ctypes.byref(ix),
+                                         ctypes.byref(dv), _p(mass), int(device)))
+    else:
+        check(lib.pyqsm_pc_laplacian(_p(pts), n, int(k), float(moll), ctypes.byref(nnz),
+                                     ctypes.byref(ip), ctypes.byref(ix), ctypes.byref(dv), _p(mass),
+                                     int(device)))
     # the library's malloc'ed outputs become the NumPy arrays themselves (91 MB per million points
     # that are not copied again); pyqsm_free runs when the last view of a buffer is gone
     indptr = _adopt(lib, ip, ctypes.c_int32, n + 1, np.int32)

@@ -1,6 +1,6 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r2k
-for cfg in "1 1" "1 8" "1 16" "4 2" "4 4" "6 3"; do set -- $cfg
-timeout -k 10 300 python tools/exp_trees.py --trees 24 --procs $1 --threads $2 >> gpurun_out/r2k/trees.log 2>&1
-done
-cat gpurun_out/r2k/trees.log | grep trees=
+mkdir -p gpurun_out/r2m
+timeout -k 10 600 python -m pytest tests/test_gpu_batch.py tests/test_gpu_laplacian.py -m gpu -q -s > gpurun_out/r2m/tests.log 2>&1; echo "tests rc=$?" >> gpurun_out/r2m/tests.log
+grep "first step\|passed\|failed" gpurun_out/r2m/tests.log
+timeout -k 10 900 python examples/config5_pipeline.py --scale 1 --skeleton-iters 20 --max-trees 100 --workers 8 > gpurun_out/r2m/config5_batch.json 2> gpurun_out/r2m/config5_batch.err
+tail -1 gpurun_out/r2m/config5_batch.json | cut -c1-600
