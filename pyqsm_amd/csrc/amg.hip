@@ -67,6 +67,12 @@ struct AmgLevel {
   // cost); same products, same bits
   float* valsdf = nullptr;
   int32_t* aggcol = nullptr;
+  // A P as its own CSR (row i: the distinct aggregates among the row's columns, entries summed).
+  // The upward sweep needs A (x + P xc) with x = Dinv b from the downward sweep, i.e. A x = b - r
+  // with the residual r that sweep stored: what is left is (A P) xc — 3-4 gathers per row from the
+  // coarse vector (a quarter of the size) instead of two gathers per entry of A.
+  int32_t *ap_ptr = nullptr, *ap_idx = nullptr;
+  float* ap_val = nullptr;
   float *r = nullptr, *xa = nullptr, *xb = nullptr, *b = nullptr;  // [n,3]; xb unused on level 0
 };
 
@@ -359,6 +365,51 @@ __global__ __launch_bounds__(256) void k_entry_cols(int n, const int32_t* __rest
   }
 }
 
+// rows of A P: count the distinct aggregates of a row (entries whose column is not represented
+// below, aggcol < 0, drop out), then fill; entry order = first occurrence in the row
+__global__ __launch_bounds__(256) void k_ap_count(int n, const int32_t* __restrict__ indptr,
+                                                  const int32_t* __restrict__ aggcol,
+                                                  int32_t* __restrict__ cnt) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i > n) return;
+  int c = 0;
+  if (i < n) {
+    const int b = indptr[i], e = indptr[i + 1];
+    for (int j = b; j < e; ++j) {
+      const int a = aggcol[j];
+      if (a < 0) continue;
+      bool seen = false;
+      for (int q = b; q < j; ++q) seen |= aggcol[q] == a;
+      c += seen ? 0 : 1;
+    }
+  }
+  cnt[i] = c;
+}
+
+__global__ __launch_bounds__(256) void k_ap_fill(int n, const int32_t* __restrict__ indptr,
+                                                 const float* __restrict__ valsf,
+                                                 const int32_t* __restrict__ aggcol,
+                                                 const int32_t* __restrict__ ap_ptr,
+                                                 int32_t* __restrict__ ap_idx,
+                                                 float* __restrict__ ap_val) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int b = indptr[i], e = indptr[i + 1];
+  int w = ap_ptr[i];
+  for (int j = b; j < e; ++j) {
+    const int a = aggcol[j];
+    if (a < 0) continue;
+    bool seen = false;
+    for (int q = b; q < j; ++q) seen |= aggcol[q] == a;
+    if (seen) continue;
+    float s = 0.f;
+    for (int q = j; q < e; ++q) s += aggcol[q] == a ? valsf[q] : 0.f;  // fixed order: deterministic
+    ap_idx[w] = a;
+    ap_val[w] = s;
+    ++w;
+  }
+}
+
 // The cycle's fp32 vectors hold one float4 (x, y, z, 0) per row: a neighbour's entry is ONE
 // 16-byte gather instead of three 4-byte ones. These kernels are bound by the number of
 // cache lines their gathers touch (the L1 takes a divergent access a line at a time), and
@@ -520,6 +571,66 @@ __global__ __launch_bounds__(256) void k_up(int n, const int32_t* __restrict__ i
     const float d = dinv[i];
     const float4 bi = ld4(b, i);
     const float o0 = y0 + d * (bi.x - a0), o1 = y1 + d * (bi.y - a1), o2 = y2 + d * (bi.z - a2);
+    st_row(out, i, o0, o1, o2);
+    if (bd) {
+      TBD e0, e1, e2;
+      ld_row(bd, i, e0, e1, e2);
+      d0 += double(e0) * double(o0);
+      d1 += double(e1) * double(o1);
+      d2 += double(e2) * double(o2);
+    }
+  }
+  if (dot) reduce3_atomic(d0, d1, d2, dot);
+}
+
+// The same upward step through A P (see AmgLevel::ap_ptr): with x = Dinv b and r = b - A x from
+// the downward sweep,  y = x + P xc,  b - A y = r - (A P) xc,  out = y + Dinv (r - (A P) xc).
+template <typename TO, typename TBD>
+__global__ __launch_bounds__(256) void k_up_ap(int n, const int32_t* __restrict__ ap_ptr,
+                                               const int32_t* __restrict__ ap_idx,
+                                               const float* __restrict__ ap_val,
+                                               const float* __restrict__ dinv,
+                                               const int32_t* __restrict__ agg,
+                                               const float* __restrict__ xc,
+                                               const float* __restrict__ r,
+                                               const float* __restrict__ x, TO* __restrict__ out,
+                                               const TBD* __restrict__ bd /*may be null*/,
+                                               double* __restrict__ dot /*may be null*/) {
+  double d0 = 0.0, d1 = 0.0, d2 = 0.0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    const int e = ap_ptr[i + 1];
+    for (int j = ap_ptr[i]; j < e; j += 4) {
+      int ac[4];
+      float v[4];
+      float4 c4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {  // past the row's end: coarse row 0 with weight 0
+        const bool ok = j + u < e;
+        ac[u] = ok ? ap_idx[j + u] : 0;
+        v[u] = ok ? ap_val[j + u] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) c4[u] = ld4(xc, ac[u]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a0 += v[u] * c4[u].x;
+        a1 += v[u] * c4[u].y;
+        a2 += v[u] * c4[u].z;
+      }
+    }
+    const int ai = agg[i];
+    const float4 xi = ld4(x, i);
+    float y0 = xi.x, y1 = xi.y, y2 = xi.z;
+    if (ai >= 0) {
+      const float4 c4 = ld4(xc, ai);
+      y0 += c4.x;
+      y1 += c4.y;
+      y2 += c4.z;
+    }
+    const float d = dinv[i];
+    const float4 ri = ld4(r, i);
+    const float o0 = y0 + d * (ri.x - a0), o1 = y1 + d * (ri.y - a1), o2 = y2 + d * (ri.z - a2);
     st_row(out, i, o0, o1, o2);
     if (bd) {
       TBD e0, e1, e2;
@@ -804,12 +915,26 @@ int amg_build(Ctx* c, const DevCsr& Lm, int n, const double* cw, const double* w
   }
   AmgLevel& last = H->lv.back();
   last.agg = nullptr;
+  const char* ape = getenv("PYQSM_AMG_AP");  // "0": the round-1 upward sweep over A (A/B comparisons)
+  const bool use_ap = !(ape && ape[0] == '0');
   for (size_t l = 0; l + 1 < H->lv.size(); ++l) {  // per-entry columns' 1/l1 and aggregate
     AmgLevel& L = H->lv[l];
     AMG_TRY(c->arena.get(size_t(L.nnz) + 1, &L.valsdf));
     AMG_TRY(c->arena.get(size_t(L.nnz) + 1, &L.aggcol));
     hipLaunchKernelGGL(k_entry_cols, dim3(ceil_div(L.n, 256)), dim3(256), 0, c->stream, L.n, L.A.indptr,
                        L.A.indices, L.valsf, L.dinvf, L.agg, L.valsdf, L.aggcol);
+    if (use_ap) {
+      AMG_TRY(c->arena.get(size_t(L.n) + 1, &L.ap_ptr));
+      hipLaunchKernelGGL(k_ap_count, dim3(ceil_div(L.n + 1, 256)), dim3(256), 0, c->stream, L.n, L.A.indptr,
+                         L.aggcol, L.ap_ptr);
+      AMG_HIP(hipGetLastError());
+      AMG_TRY(exclusive_scan_i32(c, L.ap_ptr, int64_t(L.n) + 1));
+      // at most one entry per entry of A: no read-back of the exact count
+      AMG_TRY(c->arena.get(size_t(L.nnz) + 4, &L.ap_idx));
+      AMG_TRY(c->arena.get(size_t(L.nnz) + 4, &L.ap_val));
+      hipLaunchKernelGGL(k_ap_fill, dim3(ceil_div(L.n, 256)), dim3(256), 0, c->stream, L.n, L.A.indptr,
+                         L.valsf, L.aggcol, L.ap_ptr, L.ap_idx, L.ap_val);
+    }
   }
   AMG_HIP(hipGetLastError());
   if (last.n <= kCoarseMax && H->lv.size() > 1) {
@@ -879,6 +1004,17 @@ static int vcycle_impl(Ctx* c, AmgHierarchy* H, const TV* b, TV* x, double* dot)
     AmgLevel& C = H->lv[size_t(l) + 1];
     const dim3 g(ceil_div(L.n, 256));
     ProfScope pk(c, l == 0 ? "k_up_l0" : "k_up_coarse", 1, 2);
+    if (L.ap_ptr) {
+      if (l == 0)
+        hipLaunchKernelGGL((k_up_ap<TV, TV>), dot ? dim3(std::min<int64_t>(ceil_div(L.n, 256), 1024)) : g, blk, 0,
+                           c->stream, L.n, L.ap_ptr, L.ap_idx, L.ap_val, L.dinvf, L.agg, C.xb, L.r, L.xa, x,
+                           dot ? b : static_cast<const TV*>(nullptr), dot);
+      else
+        hipLaunchKernelGGL((k_up_ap<float, float>), g, blk, 0, c->stream, L.n, L.ap_ptr, L.ap_idx, L.ap_val,
+                           L.dinvf, L.agg, C.xb, L.r, L.xa, L.xb, static_cast<const float*>(nullptr),
+                           static_cast<double*>(nullptr));
+      continue;
+    }
     if (l == 0)
       hipLaunchKernelGGL((k_up<TV, TV>), dot ? dim3(std::min<int64_t>(ceil_div(L.n, 256), 1024)) : g, blk, 0,
                          c->stream, L.n, L.A.indptr, L.A.indices, L.valsf,
