@@ -278,61 +278,35 @@ __global__ __launch_bounds__(256) void k_tri_lengths(int T, const int32_t* __res
 // the same order). One wave: 64 partials are fetched at a time, one per lane, and added one
 // after the other from registers (v_readlane) — a single lane walking the 23 000 partials of a
 // million points through dependent global loads took 1.7 ms.
-__global__ __launch_bounds__(64) void k_mollify_eps(int nblk, int T, const double* __restrict__ blk_sum,
-                                                    const double* __restrict__ blk_slack, double moll,
-                                                    double* __restrict__ eps_out) {
-  if (blockIdx.x != 0) return;
-  const int lane = threadIdx.x & 63;
+// Fold of the per-block partials into the mollification length: one block, every thread takes a
+// strided share, fixed tree (deterministic). (As one wave broadcasting one partial at a time it took
+// 1.2 ms per million points: 8 200 partials, two readlanes each, serially.)
+__global__ __launch_bounds__(256) void k_mollify_eps(int nblk, int T, const double* __restrict__ blk_sum,
+                                                     const double* __restrict__ blk_slack, double moll,
+                                                     double* __restrict__ eps_out) {
+  __shared__ double s_sum[256], s_slk[256];
   double sum = 0.0, slack = -__builtin_inf();
-  for (int base = 0; base < nblk; base += 64) {
-    const bool ok = base + lane < nblk;
-    const double s = ok ? blk_sum[base + lane] : 0.0;
-    const double k = ok ? blk_slack[base + lane] : -__builtin_inf();
-    const int cnt = min(64, nblk - base);
-    for (int l = 0; l < cnt; ++l) {
-      const double sl = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(s), l),
-                                         __builtin_amdgcn_readlane(__double2loint(s), l));
-      const double kl = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(k), l),
-                                         __builtin_amdgcn_readlane(__double2loint(k), l));
-      sum += sl;
-      if (kl > slack) slack = kl;
-    }
+  for (int b = threadIdx.x; b < nblk; b += 256) {
+    sum += blk_sum[b];
+    const double k = blk_slack[b];
+    if (k > slack) slack = k;
   }
-  if (lane != 0) return;
-  const double mean = T > 0 ? sum / (3.0 * double(T)) : 0.0;
-  const double e = slack + mean * moll;
+  s_sum[threadIdx.x] = sum;
+  s_slk[threadIdx.x] = slack;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) {
+      s_sum[threadIdx.x] += s_sum[threadIdx.x + off];
+      const double o = s_slk[threadIdx.x + off];
+      if (o > s_slk[threadIdx.x]) s_slk[threadIdx.x] = o;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
+  const double mean = T > 0 ? s_sum[0] / (3.0 * double(T)) : 0.0;
+  const double e = s_slk[0] + mean * moll;
   eps_out[0] = e > 0.0 ? e : 0.0;
 }
-
-struct Entry {  // one off-diagonal contribution
-  int32_t col;
-  int32_t key;  // 4 * triangle + slot: canonical summation order
-  double val;
-};
-
-// ---- tufted cover + intrinsic Delaunay flips (Sharp & Crane 2020, sections 4-5) ------
-//
-// Every triangle of the soup gets a front copy (face 2t, corners v0 v1 v2) and a
-// back copy (face 2t+1, corners v0 v2 v1). Around each undirected edge the incident
-// triangles are taken in a fixed order; the copy of triangle p that runs along the
-// edge from the smaller to the larger vertex id is glued to the copy of triangle
-// p+1 that runs the other way. The result is a closed oriented edge-manifold surface
-// with the same vertices, on which edges that violate the intrinsic Delaunay
-// condition (cot a + cot b < 0) are flipped using edge lengths only. Half of the
-// cotangent Laplacian of that surface is the Laplacian of the soup; after the flips
-// every edge weight is non-negative.
-//
-// Cover arrays, F = 2T faces: fv[f][c] vertex of corner c, fl[f][c] length of the
-// edge corner c -> corner c+1, fn[f][c] = 3*g + d, the face/edge glued to it.
-
-static constexpr double kDelaunayTol = 1e-10;
-static constexpr int kMaxFlipRounds = 2000;
-static constexpr int kFlipCycleLooks = 8;  // identical looks (x kFlipBatch rounds) that end a flip cycle
-static constexpr int kFlipCycleMax = 32;   // ... of at most this many flips per round
-static constexpr int kFlipBatch = 8;  // rounds queued between two looks at the counters
-
-__device__ __host__ inline int nx3(int c) { return c == 2 ? 0 : c + 1; }
-__device__ __host__ inline int pv3(int c) { return c == 0 ? 2 : c - 1; }
 
 // Several clouds in one build (extract_skeleton_batch): the mollification length is a property
 // of each cloud — max(0, its largest triangle-inequality slack + moll x its mean edge length) — so
@@ -997,7 +971,7 @@ static int pc_laplacian_impl(const double* xyz, int64_t n, const int64_t* seg_st
                          d_blk_slack);
       PQ_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(k_mollify_eps, dim3(1), dim3(64), 0, c->stream, T > 0 ? nblk : 0, T,
+    hipLaunchKernelGGL(k_mollify_eps, dim3(1), dim3(256), 0, c->stream, T > 0 ? nblk : 0, T,
                        d_blk_sum, d_blk_slack, moll, d_eps);
     double* d_eps_tri = nullptr;
     if (T > 0 && n_seg > 1) {  // one mollification length per cloud of the batch

@@ -63,12 +63,13 @@ for k in fetch:
         fk = sum(fetch[k]["FETCH_SIZE"]) / len(fetch[k]["FETCH_SIZE"])
         wk = sum(write[k]["WRITE_SIZE"]) / len(write[k]["WRITE_SIZE"])
         kern[k.replace("pyqsm::", "")] = {"fetch_size_kib": fk, "write_size_kib": wk,
-                                          "hbm_bytes_per_launch": (fk + wk) * 1024.0}
+                                          "hbm_bytes_per_launch": (2.0 * fk + wk) * 1024.0}
 json.dump({"points": 1_000_000, "kernels": kern,
-           "note": "FETCH_SIZE + WRITE_SIZE per launch from separate rocprofv3 --pmc passes "
-                   f"(profiles/{ROUND}_dbscan_pmc_*.csv), raw counter x 1024 B; the gfx950 2x correction of FETCH_SIZE "
-                   "is calibrated for 16 B/lane streaming reads only and is NOT applied (these kernels read 4-8 B per "
-                   "lane), so the figure is a lower bound of the read traffic"},
+           "note": "hbm_bytes_per_launch = 2 x FETCH_SIZE + WRITE_SIZE (KiB x 1024) from separate rocprofv3 --pmc passes "
+                   f"(profiles/{ROUND}_dbscan_pmc_*.csv). gfx950 FETCH_SIZE reports half the bytes read "
+                   "(MI355X_MICROARCH.md); calibrated on this code's own access patterns: k_bbox reads exactly 24 B per "
+                   "point (8-byte loads at a 24-byte stride) and reports 12 B; WRITE_SIZE is exact (k_union_init: 12 B "
+                   "per point). Gather-heavy kernels may deviate from the calibrated factor."},
           open(f"{OUT}/{ROUND}_dbscan_traffic.json", "w"), indent=1)
 
 
