@@ -308,6 +308,36 @@ __global__ __launch_bounds__(256) void k_mollify_eps(int nblk, int T, const doub
   eps_out[0] = e > 0.0 ? e : 0.0;
 }
 
+struct Entry {  // one off-diagonal contribution
+  int32_t col;
+  int32_t key;  // 4 * triangle + slot: canonical summation order
+  double val;
+};
+
+// ---- tufted cover + intrinsic Delaunay flips (Sharp & Crane 2020, sections 4-5) ------
+//
+// Every triangle of the soup gets a front copy (face 2t, corners v0 v1 v2) and a
+// back copy (face 2t+1, corners v0 v2 v1). Around each undirected edge the incident
+// triangles are taken in a fixed order; the copy of triangle p that runs along the
+// edge from the smaller to the larger vertex id is glued to the copy of triangle
+// p+1 that runs the other way. The result is a closed oriented edge-manifold surface
+// with the same vertices, on which edges that violate the intrinsic Delaunay
+// condition (cot a + cot b < 0) are flipped using edge lengths only. Half of the
+// cotangent Laplacian of that surface is the Laplacian of the soup; after the flips
+// every edge weight is non-negative.
+//
+// Cover arrays, F = 2T faces: fv[f][c] vertex of corner c, fl[f][c] length of the
+// edge corner c -> corner c+1, fn[f][c] = 3*g + d, the face/edge glued to it.
+
+static constexpr double kDelaunayTol = 1e-10;
+static constexpr int kMaxFlipRounds = 2000;
+static constexpr int kFlipCycleLooks = 8;  // identical looks (x kFlipBatch rounds) that end a flip cycle
+static constexpr int kFlipCycleMax = 32;   // ... of at most this many flips per round
+static constexpr int kFlipBatch = 8;  // rounds queued between two looks at the counters
+
+__device__ __host__ inline int nx3(int c) { return c == 2 ? 0 : c + 1; }
+__device__ __host__ inline int pv3(int c) { return c == 0 ? 2 : c - 1; }
+
 // Several clouds in one build (extract_skeleton_batch): the mollification length is a property
 // of each cloud — max(0, its largest triangle-inequality slack + moll x its mean edge length) — so
 // it is reduced per SEGMENT of points. Triangles are stored fan by fan in point order, so the
