@@ -341,7 +341,7 @@ __constant__ signed char kSubOffsets[62][3] = {{1,0,0}, {-1,1,0}, {0,1,0}, {1,1,
 // Sub-cells one wave of the two passes below takes: a wave per sub-cell (200 k waves of a
 // few hundred cycles each per million points) was bound by the rate at which waves START
 // (resident waves: 13-21 % of the slots), not by what they did.
-static constexpr int kSubPerWave = 4;
+static constexpr int kSubPerWaveDefault = 4;
 
 // Full path compression for the listed representatives (plain accesses: the kernel
 // boundary makes the unions of the previous launch visible, and any value another lane
@@ -362,6 +362,7 @@ __global__ __launch_bounds__(256) void k_flatten_reps(const int4* __restrict__ l
 // no cycle, every sub-cell writes its own pointer only (plain store, no atomics, no
 // chasing), and what remains after compression is a few trees per cluster — one per
 // sub-cell without a connected smaller neighbour. One wave per sub-cell as below.
+template <int kSubPerWave>
 __global__ __launch_bounds__(256) void k_hook_sub(const int4* __restrict__ list, int m, int nx,
                                                   int ny, const int32_t* __restrict__ start,
                                                   const int4* __restrict__ rec,
@@ -455,6 +456,7 @@ __global__ __launch_bounds__(256) void k_hook_sub(const int4* __restrict__ list,
 // tests all |S1| x |S2| point pairs at once, 64 per step. (A lane per pair of sub-cells
 // running the pair loop itself was 3x slower: ~25 dependent iterations per lane, and a wave
 // lasts as long as its slowest lane.)
+template <int kSubPerWave>
 __global__ __launch_bounds__(256) void k_union_sub(const int4* __restrict__ list, int m,
                                                    const int32_t* __restrict__ nbr,
                                                    const int32_t* __restrict__ sub_of,
@@ -770,21 +772,40 @@ static int dbscan_device(Ctx* c, const double* xyz, int64_t n, double eps, int32
       PQ_HIP(hipMemcpyAsync(&m, list_cnt, 4, hipMemcpyDeviceToHost, c->stream));
       PQ_HIP(hipStreamSynchronize(c->stream));
       if (m > 0) {
-        const dim3 gw(ceil_div(m, 4 * kSubPerWave)), gl(ceil_div(m, 256));
+        static const int spw = [] {  // PYQSM_SUB_PER_WAVE: sub-cells one wave takes (2, 4 or 8)
+          const char* e = getenv("PYQSM_SUB_PER_WAVE");
+          const int v = e ? atoi(e) : kSubPerWaveDefault;
+          return (v == 2 || v == 8) ? v : 4;
+        }();
+        const dim3 gw(ceil_div(m, 4 * spw)), gl(ceil_div(m, 256));
         int32_t* nbr;  // [m][64] representatives of the neighbour sub-cells pass 1 resolved
         PQ_TRY(c->arena.get(size_t(m) * 64, &nbr));
         {
           ProfScope pk(c, "k_hook_sub");
-          hipLaunchKernelGGL(k_hook_sub, gw, block, 0, c->stream, list, m, g.nx, g.ny, g.start, sub.rec,
-                             g.sx, g.sy, g.sz, r2, core, parent, nbr);
+          if (spw == 2)
+            hipLaunchKernelGGL(k_hook_sub<2>, gw, block, 0, c->stream, list, m, g.nx, g.ny, g.start, sub.rec,
+                               g.sx, g.sy, g.sz, r2, core, parent, nbr);
+          else if (spw == 8)
+            hipLaunchKernelGGL(k_hook_sub<8>, gw, block, 0, c->stream, list, m, g.nx, g.ny, g.start, sub.rec,
+                               g.sx, g.sy, g.sz, r2, core, parent, nbr);
+          else
+            hipLaunchKernelGGL(k_hook_sub<4>, gw, block, 0, c->stream, list, m, g.nx, g.ny, g.start, sub.rec,
+                               g.sx, g.sy, g.sz, r2, core, parent, nbr);
         }
         hipLaunchKernelGGL(k_flatten_reps, gl, block, 0, c->stream, list, m, parent);
         // what is left: joining the few trees per cluster. Almost every pair of neighbours
         // now shows the same root through two plain loads.
         {
           ProfScope pk(c, "k_union_sub");
-          hipLaunchKernelGGL(k_union_sub, gw, block, 0, c->stream, list, m, nbr, sub.sub_of, sub.rec,
-                             g.sx, g.sy, g.sz, r2, core, parent);
+          if (spw == 2)
+            hipLaunchKernelGGL(k_union_sub<2>, gw, block, 0, c->stream, list, m, nbr, sub.sub_of, sub.rec,
+                               g.sx, g.sy, g.sz, r2, core, parent);
+          else if (spw == 8)
+            hipLaunchKernelGGL(k_union_sub<8>, gw, block, 0, c->stream, list, m, nbr, sub.sub_of, sub.rec,
+                               g.sx, g.sy, g.sz, r2, core, parent);
+          else
+            hipLaunchKernelGGL(k_union_sub<4>, gw, block, 0, c->stream, list, m, nbr, sub.sub_of, sub.rec,
+                               g.sx, g.sy, g.sz, r2, core, parent);
         }
         hipLaunchKernelGGL(k_flatten_reps, gl, block, 0, c->stream, list, m, parent);
         hipLaunchKernelGGL(k_rep_min, gl, block, 0, c->stream, list, m, parent, run_min, min_orig);
