@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--contraction", type=float, default=3)
     ap.add_argument("--attraction", type=float, default=3)
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--engine", default="python", help="python (loop over the C-ABI calls) or native "
+                                                         "(pyqsm_extract_skeleton: the whole loop in HBM)")
     args = ap.parse_args()
     if args.verbose:
         logging.basicConfig(level=logging.INFO)
@@ -37,13 +39,13 @@ def main():
     t0 = time.perf_counter()
     got, total, steps = sk.extract_skeleton(pts, max_iter=args.iters, termination_ratio=0.0,
                                             contraction_factor=args.contraction,
-                                            attraction_factor=args.attraction)
+                                            attraction_factor=args.attraction, engine=args.engine)
     wall = time.perf_counter() - t0
     prof = {k: hip.prof_get(k) for k in ("lap_knn", "lap_fans", "lap_assemble", "lbc_inner_iter",
                                          "lbc_amg_iter", "lbc_amg_build",
                                          "lbc_outer_iter", "lbc_cg_iter", "clamp")}
     out = {"config": f"{args.points}-point forest, {len(steps)} contraction steps, "
-                     f"init_contraction={args.contraction}",
+                     f"init_contraction={args.contraction}, engine={args.engine}",
            "wall_s": wall, "s_per_iteration": wall / max(len(steps), 1),
            "laplacian_ms": sum(prof[k][0] for k in ("lap_knn", "lap_fans", "lap_assemble")),
            "solve_multigrid_cg_iterations": prof["lbc_amg_iter"][1],

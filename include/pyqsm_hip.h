@@ -325,6 +325,33 @@ int pyqsm_pc_laplacian_seg(const double* xyz, int64_t n, const int64_t* seg_star
                            int32_t k, double moll, int64_t* nnz, int32_t** indptr,
                            int32_t** indices, double** vals, double* mass, int32_t device);
 
+/* ---- the whole contraction loop, resident in HBM ------------------------------ */
+/*
+ * extract_skeleton of pyQSM/geometry/skeletonize.py:240-373 as ONE call: Laplacian ->
+ * contraction solve -> clamp (:291-296) -> weights (:329-335) -> next Laplacian, up to
+ * max_iter times, with the points, the matrix and the weights staying on the device
+ * (the Python loop moves ~200 MB over PCIe per step at one million points). The loop's
+ * bookkeeping is the reference's (W_H updated with the mass of the Laplacian just used,
+ * volume ratio lagging one step, stop when a solve changes nothing or returns only NaN).
+ *   xyz f64 [n,3]; seg_start i64 [n_seg+1] (NULL with n_seg = 1): several clouds stacked
+ *   into one array are contracted together — one build and one block-diagonal solve per
+ *   step — while weights, clamp box, volume ratio and termination stay per cloud;
+ *   lo, hi f64 [n_seg,3]: the clamp box of every cloud (the reference takes the min / max
+ *   bound of the oriented bounding box, :240-241); rtol, solver_max_it as pyqsm_lbc_solve.
+ *   out_pts, total_shift f64 [n,3]; steps f64 [max(max_iter,1), n, 3] or NULL: the shift of
+ *   every step (zero for clouds that had stopped); n_steps i32 [n_seg]: steps each cloud
+ *   took; solve_iters i32 / solve_resid f64 / solve_ok u8 [max(max_iter,1)] (each may be
+ *   NULL): per solve, as pyqsm_lbc_solve reports them; *n_solves: solves run.
+ */
+int pyqsm_extract_skeleton(const double* xyz, int64_t n, const int64_t* seg_start, int64_t n_seg,
+                           int32_t k, double moll, int32_t max_iter, double termination_ratio,
+                           double contraction_factor, double attraction_factor,
+                           double max_contraction, double max_attraction, const double* lo,
+                           const double* hi, double rtol, int32_t solver_max_it, double* out_pts,
+                           double* total_shift, double* steps, int32_t* n_steps,
+                           int32_t* solve_iters, double* solve_resid, uint8_t* solve_ok,
+                           int32_t* n_solves, int32_t device);
+
 #ifdef __cplusplus
 }
 #endif

@@ -67,6 +67,8 @@ SIGNATURES = {
     "pyqsm_pc_laplacian": (ctypes.c_int, [vp, i64, i32, dbl, ctypes.POINTER(i64),
                                           ctypes.POINTER(vp), ctypes.POINTER(vp),
                                           ctypes.POINTER(vp), vp, i32]),
+    "pyqsm_extract_skeleton": (ctypes.c_int, [vp, i64, vp, i64, i32, dbl, i32, dbl, dbl, dbl, dbl, dbl, vp, vp,
+                                              dbl, i32, vp, vp, vp, vp, vp, vp, vp, ctypes.POINTER(i32), i32]),
     "pyqsm_pc_laplacian_seg": (ctypes.c_int, [vp, i64, vp, i64, i32, dbl, ctypes.POINTER(i64),
                                               ctypes.POINTER(vp), ctypes.POINTER(vp),
                                               ctypes.POINTER(vp), vp, i32]),

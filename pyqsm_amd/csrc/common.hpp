@@ -54,6 +54,13 @@ class Arena {
   }
   int reset();
   void destroy();
+  // Position of the allocator; rewind(mark) releases everything allocated after mark() (chunks
+  // added meanwhile stay and are reused). For long calls that loop over large temporaries.
+  struct Mark {
+    size_t chunk, used;
+  };
+  Mark mark() const;
+  void rewind(const Mark& m);
 
  private:
   struct Chunk {
@@ -62,6 +69,7 @@ class Arena {
     size_t used;
   };
   std::vector<Chunk> chunks_;
+  size_t cur_ = 0;  // chunk allocations currently come from
 };
 
 struct Timer {
@@ -116,6 +124,16 @@ class ApiRange {
 void comm_shutdown();
 
 inline int ceil_div(int64_t a, int64_t b) { return static_cast<int>((a + b - 1) / b); }
+
+// Device-resident pieces other translation units chain (skeleton.hip runs the whole contraction
+// loop in HBM): kNN, the point-cloud Laplacian, the contraction solve.
+struct LapOut {  // all pointers into the context arena
+  int32_t *indptr, *indices;
+  double *vals, *mass;
+  int32_t nnz;
+};
+int laplacian_device(Ctx* c, const double* d_xyz, int64_t n, const int64_t* seg_start /*host, may be null*/,
+                     int64_t n_seg, int32_t k, double moll, LapOut* out);
 
 // Exclusive prefix sum of n int32 values, in place, on the stream (scan.hip).
 int exclusive_scan_i32(Ctx* c, int32_t* data, int64_t n);

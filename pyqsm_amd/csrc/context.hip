@@ -56,13 +56,15 @@ static constexpr size_t kAlign = 256;
 int Arena::alloc(size_t bytes, void** out) {
   bytes = (bytes + kAlign - 1) / kAlign * kAlign;
   if (bytes == 0) bytes = kAlign;
-  if (!chunks_.empty()) {
-    Chunk& c = chunks_.back();
+  // bump inside the current chunk, else move on to a later (empty) chunk that is large enough
+  for (; cur_ < chunks_.size(); ++cur_) {
+    Chunk& c = chunks_[cur_];
     if (c.used + bytes <= c.size) {
       *out = c.base + c.used;
       c.used += bytes;
       return 0;
     }
+    if (cur_ + 1 == chunks_.size()) break;
   }
   size_t want = bytes;
   if (want < (size_t(64) << 20)) want = size_t(64) << 20;
@@ -76,6 +78,7 @@ int Arena::alloc(size_t bytes, void** out) {
     return fail(PYQSM_ENOMEM, "scratch arena: hipMalloc(%zu) failed: %s", want,
                 hipGetErrorString(e));
   chunks_.push_back({static_cast<char*>(p), want, bytes});
+  cur_ = chunks_.size() - 1;
   *out = p;
   return 0;
 }
@@ -93,12 +96,28 @@ int Arena::reset() {
   } else if (chunks_.size() == 1) {
     chunks_[0].used = 0;
   }
+  cur_ = 0;
   return 0;
+}
+
+Arena::Mark Arena::mark() const {
+  if (chunks_.empty()) return Mark{0, 0};
+  return Mark{cur_, chunks_[cur_].used};
+}
+
+void Arena::rewind(const Mark& m) {
+  if (chunks_.empty()) return;
+  for (size_t i = m.chunk + 1; i < chunks_.size(); ++i) chunks_[i].used = 0;
+  if (m.chunk < chunks_.size()) {
+    chunks_[m.chunk].used = m.used;
+    cur_ = m.chunk;
+  }
 }
 
 void Arena::destroy() {
   for (auto& c : chunks_) (void)hipFree(c.base);
   chunks_.clear();
+  cur_ = 0;
 }
 
 // ---- page-locked output buffers ----------------------------------------------------------

@@ -891,6 +891,208 @@ using namespace pyqsm;
 
 extern "C" {
 
+}  // extern "C"
+
+namespace pyqsm {
+
+// The build itself, device-resident: d_xyz in, CSR + mass left in the context arena.
+int laplacian_device(Ctx* c, const double* d_xyz, int64_t n, const int64_t* seg_start, int64_t n_seg,
+                     int32_t k, double moll, LapOut* out) {
+  const int N = int(n);
+  int32_t* d_nbr;
+  double* d_d2;
+  PQ_TRY(c->arena.get(size_t(n) * k, &d_nbr));
+  PQ_TRY(c->arena.get(size_t(n) * k, &d_d2));
+  {
+    ProfScope ps(c, "lap_knn");
+    PQ_TRY(knn_device(c, d_xyz, n, k, 1, d_nbr, d_d2));
+  }
+  int32_t *d_tri, *d_tcount;
+  PQ_TRY(c->arena.get(size_t(n) * k * 2, &d_tri));
+  PQ_TRY(c->arena.get(size_t(n) + 1, &d_tcount));
+  PQ_HIP(hipMemsetAsync(d_tcount, 0, (size_t(n) + 1) * 4, c->stream));
+  {
+    ProfScope ps(c, "lap_fans");
+    if (k <= 32)
+      hipLaunchKernelGGL(k_fans<2>, dim3(ceil_div(n, 8)), dim3(256), 0, c->stream, N, k, d_xyz, d_nbr, d_tri,
+                         d_tcount);
+    else
+      hipLaunchKernelGGL(k_fans<1>, dim3(ceil_div(n, 4)), dim3(256), 0, c->stream, N, k, d_xyz, d_nbr, d_tri,
+                         d_tcount);
+    PQ_HIP(hipGetLastError());
+  }
+  ProfScope ps(c, "lap_assemble");
+  PQ_TRY(exclusive_scan_i32(c, d_tcount, n + 1));
+  int32_t T = 0;
+  PQ_HIP(hipMemcpyAsync(&T, d_tcount + n, 4, hipMemcpyDeviceToHost, c->stream));
+  PQ_HIP(hipStreamSynchronize(c->stream));
+  int32_t *d_tris, *d_vcount, *d_cursor, *d_nnzrow, *d_fv, *d_fn, *d_bcount, *d_bcursor,
+      *d_cnt, *d_mark, *d_list[2];
+  unsigned long long* d_claim;
+  uint8_t* d_iscand;
+  double *d_len, *d_area, *d_blk_sum, *d_blk_slack, *d_eps, *d_mass, *d_fl;
+  Entry* d_ent;
+  EdgeRec* d_rec;
+  const int F = 2 * T;  // cover faces
+  const int nblk = ceil_div(std::max<int64_t>(T, 1), 256);
+  PQ_TRY(c->arena.get(size_t(T) * 3 + 1, &d_tris));
+  PQ_TRY(c->arena.get(size_t(T) * 3 + 1, &d_len));
+  PQ_TRY(c->arena.get(size_t(F) + 1, &d_area));
+  PQ_TRY(c->arena.get(size_t(nblk), &d_blk_sum));
+  PQ_TRY(c->arena.get(size_t(nblk), &d_blk_slack));
+  PQ_TRY(c->arena.get(1, &d_eps));
+  PQ_TRY(c->arena.get(size_t(n) + 1, &d_vcount));
+  PQ_TRY(c->arena.get(size_t(n), &d_cursor));
+  PQ_TRY(c->arena.get(size_t(n) + 1, &d_nnzrow));
+  PQ_TRY(c->arena.get(size_t(F) * 6 + 1, &d_ent));
+  PQ_TRY(c->arena.get(size_t(n), &d_mass));
+  PQ_TRY(c->arena.get(size_t(F) * 3 + 1, &d_fv));
+  PQ_TRY(c->arena.get(size_t(F) * 3 + 1, &d_fl));
+  PQ_TRY(c->arena.get(size_t(F) * 3 + 1, &d_fn));
+  PQ_TRY(c->arena.get(size_t(n) + 1, &d_bcount));
+  PQ_TRY(c->arena.get(size_t(n), &d_bcursor));
+  PQ_TRY(c->arena.get(size_t(T) * 3 + 1, &d_rec));
+  PQ_TRY(c->arena.get(size_t(F) + 1, &d_claim));
+  PQ_TRY(c->arena.get(size_t(F) * 3 + 1, &d_mark));
+  PQ_TRY(c->arena.get(size_t(F) * 3 + 1, &d_list[0]));
+  PQ_TRY(c->arena.get(size_t(F) * 3 + 1, &d_list[1]));
+  PQ_TRY(c->arena.get(size_t(F) * 3 + 1, &d_iscand));
+  PQ_TRY(c->arena.get(size_t(kMaxFlipRounds + 2) * 2, &d_cnt));
+  PQ_HIP(hipMemsetAsync(d_vcount, 0, (size_t(n) + 1) * 4, c->stream));
+  PQ_HIP(hipMemsetAsync(d_cursor, 0, size_t(n) * 4, c->stream));
+  PQ_HIP(hipMemsetAsync(d_nnzrow, 0, (size_t(n) + 1) * 4, c->stream));
+  PQ_HIP(hipMemsetAsync(d_bcount, 0, (size_t(n) + 1) * 4, c->stream));
+  PQ_HIP(hipMemsetAsync(d_bcursor, 0, size_t(n) * 4, c->stream));
+  const dim3 gn(ceil_div(n, 256)), gt(nblk), blk(256);
+  const dim3 gf(ceil_div(std::max(F, 1), 256)), gh(ceil_div(std::max(3 * F, 1), 256));
+  if (T > 0) {
+    hipLaunchKernelGGL(k_compact_tris, gn, blk, 0, c->stream, N, k, d_tri, d_tcount, d_tris);
+    hipLaunchKernelGGL(k_tri_lengths, gt, blk, 0, c->stream, T, d_tris, d_xyz, d_len, d_blk_sum,
+                       d_blk_slack);
+    PQ_HIP(hipGetLastError());
+  }
+  hipLaunchKernelGGL(k_mollify_eps, dim3(1), dim3(256), 0, c->stream, T > 0 ? nblk : 0, T,
+                     d_blk_sum, d_blk_slack, moll, d_eps);
+  double* d_eps_tri = nullptr;
+  if (T > 0 && n_seg > 1) {  // one mollification length per cloud of the batch
+    int32_t *d_seg_start, *d_tstart;
+    double* d_eps_seg;
+    PQ_TRY(c->arena.get(size_t(n_seg) + 1, &d_seg_start));
+    PQ_TRY(c->arena.get(size_t(n_seg) + 1, &d_tstart));
+    PQ_TRY(c->arena.get(size_t(n_seg), &d_eps_seg));
+    PQ_TRY(c->arena.get(size_t(T), &d_eps_tri));
+    std::vector<int32_t> h32(size_t(n_seg) + 1);
+    for (int64_t q = 0; q <= n_seg; ++q) h32[size_t(q)] = int32_t(seg_start[q]);
+    PQ_HIP(hipMemcpyAsync(d_seg_start, h32.data(), (size_t(n_seg) + 1) * 4, hipMemcpyHostToDevice,
+                          c->stream));
+    hipLaunchKernelGGL(k_seg_eps, dim3(unsigned(n_seg)), blk, 0, c->stream, int(n_seg), d_seg_start, d_tcount,
+                       d_len, moll, d_tstart, d_eps_seg);
+    hipLaunchKernelGGL(k_tri_eps, gt, blk, 0, c->stream, T, int(n_seg), d_tstart, d_eps_seg, d_eps_tri);
+    PQ_HIP(hipGetLastError());
+    PQ_HIP(hipStreamSynchronize(c->stream));  // h32 goes out of scope
+  }
+  if (T > 0) {
+    // tufted cover: two faces per triangle, glued around every edge
+    hipLaunchKernelGGL(k_cover_init, gt, blk, 0, c->stream, T, d_tris, d_len, d_eps, d_eps_tri, d_fv, d_fl,
+                       d_bcount);
+    PQ_TRY(exclusive_scan_i32(c, d_bcount, n + 1));
+    hipLaunchKernelGGL(k_edge_scatter, gt, blk, 0, c->stream, T, d_tris, d_bcount, d_bcursor,
+                       d_rec);
+    hipLaunchKernelGGL(k_glue, gn, blk, 0, c->stream, N, d_bcount, d_rec, d_fn);
+    PQ_HIP(hipGetLastError());
+    // intrinsic Delaunay flips: rounds of conflict-free flips until none is left
+    ProfScope pf(c, "lap_flips");
+    PQ_HIP(hipMemsetAsync(d_claim, 0, (size_t(F) + 1) * 8, c->stream));
+    PQ_HIP(hipMemsetAsync(d_mark, 0, (size_t(F) * 3 + 1) * 4, c->stream));
+    // counters: slot 0 = seeding pass, slot r + 1 = round r: {next list length, flips}
+    PQ_HIP(hipMemsetAsync(d_cnt, 0, size_t(kMaxFlipRounds + 2) * 8, c->stream));
+    hipLaunchKernelGGL(k_flip_seed, gh, blk, 0, c->stream, 3 * F, d_fl, d_fn, d_list[0], d_cnt);
+    int32_t hc[2] = {0, 0};
+    PQ_HIP(hipMemcpyAsync(hc, d_cnt, 8, hipMemcpyDeviceToHost, c->stream));
+    PQ_HIP(hipStreamSynchronize(c->stream));
+    int m = hc[0];  // last list length the host has seen (sizes the next launches)
+    int last_flips = -1, same_looks = 0;
+    for (int round = 0; round < kMaxFlipRounds && m > 0;) {
+      // a batch of rounds between two looks at the counters; the lists shrink fast, and a
+      // kernel whose list is longer than its grid covers simply strides
+      const dim3 gm(unsigned(std::min<int64_t>(ceil_div(m, 256), 4096)));
+      const int batch_end = std::min(round + kFlipBatch, kMaxFlipRounds);
+      for (; round < batch_end; ++round) {
+        const int32_t* cur = d_list[round & 1];
+        int32_t* nxt = d_list[(round & 1) ^ 1];
+        const unsigned long long stamp = (unsigned long long)(round + 1) << 32;
+        hipLaunchKernelGGL(k_flip_claim, gm, blk, 0, c->stream, d_cnt + 2 * round, cur, stamp, d_fl,
+                           d_fn, d_claim, d_iscand);
+        hipLaunchKernelGGL(k_flip_apply, gm, blk, 0, c->stream, d_cnt + 2 * round, cur, d_iscand, stamp,
+                           round, d_fv, d_fl, d_fn, d_claim, d_mark, nxt, d_cnt + 2 * (round + 1));
+      }
+      PQ_HIP(hipGetLastError());
+      PQ_HIP(hipMemcpyAsync(hc, d_cnt + 2 * round, 8, hipMemcpyDeviceToHost, c->stream));
+      PQ_HIP(hipStreamSynchronize(c->stream));
+      if (hc[1] == 0) break;  // the last round of the batch flipped nothing: done (or stuck)
+      // A handful of edges flipping back and forth for good: on nearly degenerate faces of
+      // a contracted cloud the rounding of the two cotangents can exceed the tolerance on
+      // both sides of a flip (seen: 2 flips a round from round 88 to the cap, 35 ms per
+      // build of a 50 k-point tree). The same few flips with the same list for
+      // kFlipCycleLooks looks in a row end the loop; either state of such an edge is as
+      // Delaunay as fp64 can tell.
+      if (hc[0] == m && hc[1] == last_flips && hc[1] <= kFlipCycleMax) {
+        if (++same_looks >= kFlipCycleLooks) break;
+      } else {
+        same_looks = 0;
+      }
+      last_flips = hc[1];
+      m = hc[0];
+      if (getenv("PYQSM_LBC_TRACE")) fprintf(stderr, "flip round %d list %d flips(last) %d\n", round, hc[0], hc[1]);
+    }
+    hipLaunchKernelGGL(k_cover_vcount, gf, blk, 0, c->stream, F, d_fv, d_vcount);
+  }
+  PQ_TRY(exclusive_scan_i32(c, d_vcount, n + 1));  // row_start of the contributions
+  if (T > 0) {
+    hipLaunchKernelGGL(k_cover_weights, gf, blk, 0, c->stream, F, d_fv, d_fl, d_vcount, d_cursor,
+                       d_ent, d_area);
+    PQ_HIP(hipGetLastError());
+  }
+  if (getenv("PYQSM_LBC_TRACE")) {  // longest row of contributions
+    std::vector<int32_t> rs(size_t(n) + 1);
+    PQ_HIP(hipMemcpyAsync(rs.data(), d_vcount, (size_t(n) + 1) * 4, hipMemcpyDeviceToHost, c->stream));
+    PQ_HIP(hipStreamSynchronize(c->stream));
+    int mx = 0;
+    int64_t over = 0;
+    for (int64_t i = 0; i < n; ++i) {
+      const int len = rs[size_t(i) + 1] - rs[size_t(i)];
+      mx = std::max(mx, len);
+      over += len > 64 * kSortPer;
+    }
+    fprintf(stderr, "laplacian rows: %d contributions at most, %lld rows beyond the wave path\n", mx,
+            (long long)over);
+  }
+  hipLaunchKernelGGL(k_sort_rows, dim3(ceil_div(n, 4)), blk, 0, c->stream, N, d_vcount, d_ent,
+                     d_nnzrow);
+  PQ_HIP(hipGetLastError());
+  PQ_TRY(exclusive_scan_i32(c, d_nnzrow, n + 1));  // indptr
+  int32_t nnz = 0;
+  PQ_HIP(hipMemcpyAsync(&nnz, d_nnzrow + n, 4, hipMemcpyDeviceToHost, c->stream));
+  PQ_HIP(hipStreamSynchronize(c->stream));
+  int32_t* d_indices;
+  double* d_vals;
+  PQ_TRY(c->arena.get(size_t(nnz) + 1, &d_indices));
+  PQ_TRY(c->arena.get(size_t(nnz) + 1, &d_vals));
+  hipLaunchKernelGGL(k_rows, gn, blk, 0, c->stream, N, d_vcount, d_ent, d_area, d_nnzrow, d_indices,
+                     d_vals, d_mass);
+  PQ_HIP(hipGetLastError());
+  out->indptr = d_nnzrow;
+  out->indices = d_indices;
+  out->vals = d_vals;
+  out->mass = d_mass;
+  out->nnz = nnz;
+  return 0;
+}
+
+}  // namespace pyqsm
+
+extern "C" {
+
 static int pc_laplacian_impl(const double* xyz, int64_t n, const int64_t* seg_start, int64_t n_seg,
                              int32_t k, double moll, int64_t* nnz_out, int32_t** indptr_out,
                              int32_t** indices_out, double** vals_out, double* mass, int32_t device) {
@@ -925,192 +1127,14 @@ static int pc_laplacian_impl(const double* xyz, int64_t n, const int64_t* seg_st
   }
   int rc = 0;
   auto body = [&]() -> int {
-    const int N = int(n);
     double* d_xyz;
-    int32_t* d_nbr;
-    double* d_d2;
     PQ_TRY(c->arena.get(size_t(n) * 3, &d_xyz));
-    PQ_TRY(c->arena.get(size_t(n) * k, &d_nbr));
-    PQ_TRY(c->arena.get(size_t(n) * k, &d_d2));
     PQ_HIP(hipMemcpyAsync(d_xyz, xyz, size_t(n) * 24, hipMemcpyHostToDevice, c->stream));
-    {
-      ProfScope ps(c, "lap_knn");
-      PQ_TRY(knn_device(c, d_xyz, n, k, 1, d_nbr, d_d2));
-    }
-    int32_t *d_tri, *d_tcount;
-    PQ_TRY(c->arena.get(size_t(n) * k * 2, &d_tri));
-    PQ_TRY(c->arena.get(size_t(n) + 1, &d_tcount));
-    PQ_HIP(hipMemsetAsync(d_tcount, 0, (size_t(n) + 1) * 4, c->stream));
-    {
-      ProfScope ps(c, "lap_fans");
-      if (k <= 32)
-        hipLaunchKernelGGL(k_fans<2>, dim3(ceil_div(n, 8)), dim3(256), 0, c->stream, N, k, d_xyz, d_nbr, d_tri,
-                           d_tcount);
-      else
-        hipLaunchKernelGGL(k_fans<1>, dim3(ceil_div(n, 4)), dim3(256), 0, c->stream, N, k, d_xyz, d_nbr, d_tri,
-                           d_tcount);
-      PQ_HIP(hipGetLastError());
-    }
-    ProfScope ps(c, "lap_assemble");
-    PQ_TRY(exclusive_scan_i32(c, d_tcount, n + 1));
-    int32_t T = 0;
-    PQ_HIP(hipMemcpyAsync(&T, d_tcount + n, 4, hipMemcpyDeviceToHost, c->stream));
-    PQ_HIP(hipStreamSynchronize(c->stream));
-    int32_t *d_tris, *d_vcount, *d_cursor, *d_nnzrow, *d_fv, *d_fn, *d_bcount, *d_bcursor,
-        *d_cnt, *d_mark, *d_list[2];
-    unsigned long long* d_claim;
-    uint8_t* d_iscand;
-    double *d_len, *d_area, *d_blk_sum, *d_blk_slack, *d_eps, *d_mass, *d_fl;
-    Entry* d_ent;
-    EdgeRec* d_rec;
-    const int F = 2 * T;  // cover faces
-    const int nblk = ceil_div(std::max<int64_t>(T, 1), 256);
-    PQ_TRY(c->arena.get(size_t(T) * 3 + 1, &d_tris));
-    PQ_TRY(c->arena.get(size_t(T) * 3 + 1, &d_len));
-    PQ_TRY(c->arena.get(size_t(F) + 1, &d_area));
-    PQ_TRY(c->arena.get(size_t(nblk), &d_blk_sum));
-    PQ_TRY(c->arena.get(size_t(nblk), &d_blk_slack));
-    PQ_TRY(c->arena.get(1, &d_eps));
-    PQ_TRY(c->arena.get(size_t(n) + 1, &d_vcount));
-    PQ_TRY(c->arena.get(size_t(n), &d_cursor));
-    PQ_TRY(c->arena.get(size_t(n) + 1, &d_nnzrow));
-    PQ_TRY(c->arena.get(size_t(F) * 6 + 1, &d_ent));
-    PQ_TRY(c->arena.get(size_t(n), &d_mass));
-    PQ_TRY(c->arena.get(size_t(F) * 3 + 1, &d_fv));
-    PQ_TRY(c->arena.get(size_t(F) * 3 + 1, &d_fl));
-    PQ_TRY(c->arena.get(size_t(F) * 3 + 1, &d_fn));
-    PQ_TRY(c->arena.get(size_t(n) + 1, &d_bcount));
-    PQ_TRY(c->arena.get(size_t(n), &d_bcursor));
-    PQ_TRY(c->arena.get(size_t(T) * 3 + 1, &d_rec));
-    PQ_TRY(c->arena.get(size_t(F) + 1, &d_claim));
-    PQ_TRY(c->arena.get(size_t(F) * 3 + 1, &d_mark));
-    PQ_TRY(c->arena.get(size_t(F) * 3 + 1, &d_list[0]));
-    PQ_TRY(c->arena.get(size_t(F) * 3 + 1, &d_list[1]));
-    PQ_TRY(c->arena.get(size_t(F) * 3 + 1, &d_iscand));
-    PQ_TRY(c->arena.get(size_t(kMaxFlipRounds + 2) * 2, &d_cnt));
-    PQ_HIP(hipMemsetAsync(d_vcount, 0, (size_t(n) + 1) * 4, c->stream));
-    PQ_HIP(hipMemsetAsync(d_cursor, 0, size_t(n) * 4, c->stream));
-    PQ_HIP(hipMemsetAsync(d_nnzrow, 0, (size_t(n) + 1) * 4, c->stream));
-    PQ_HIP(hipMemsetAsync(d_bcount, 0, (size_t(n) + 1) * 4, c->stream));
-    PQ_HIP(hipMemsetAsync(d_bcursor, 0, size_t(n) * 4, c->stream));
-    const dim3 gn(ceil_div(n, 256)), gt(nblk), blk(256);
-    const dim3 gf(ceil_div(std::max(F, 1), 256)), gh(ceil_div(std::max(3 * F, 1), 256));
-    if (T > 0) {
-      hipLaunchKernelGGL(k_compact_tris, gn, blk, 0, c->stream, N, k, d_tri, d_tcount, d_tris);
-      hipLaunchKernelGGL(k_tri_lengths, gt, blk, 0, c->stream, T, d_tris, d_xyz, d_len, d_blk_sum,
-                         d_blk_slack);
-      PQ_HIP(hipGetLastError());
-    }
-    hipLaunchKernelGGL(k_mollify_eps, dim3(1), dim3(256), 0, c->stream, T > 0 ? nblk : 0, T,
-                       d_blk_sum, d_blk_slack, moll, d_eps);
-    double* d_eps_tri = nullptr;
-    if (T > 0 && n_seg > 1) {  // one mollification length per cloud of the batch
-      int32_t *d_seg_start, *d_tstart;
-      double* d_eps_seg;
-      PQ_TRY(c->arena.get(size_t(n_seg) + 1, &d_seg_start));
-      PQ_TRY(c->arena.get(size_t(n_seg) + 1, &d_tstart));
-      PQ_TRY(c->arena.get(size_t(n_seg), &d_eps_seg));
-      PQ_TRY(c->arena.get(size_t(T), &d_eps_tri));
-      std::vector<int32_t> h32(size_t(n_seg) + 1);
-      for (int64_t q = 0; q <= n_seg; ++q) h32[size_t(q)] = int32_t(seg_start[q]);
-      PQ_HIP(hipMemcpyAsync(d_seg_start, h32.data(), (size_t(n_seg) + 1) * 4, hipMemcpyHostToDevice,
-                            c->stream));
-      hipLaunchKernelGGL(k_seg_eps, dim3(unsigned(n_seg)), blk, 0, c->stream, int(n_seg), d_seg_start, d_tcount,
-                         d_len, moll, d_tstart, d_eps_seg);
-      hipLaunchKernelGGL(k_tri_eps, gt, blk, 0, c->stream, T, int(n_seg), d_tstart, d_eps_seg, d_eps_tri);
-      PQ_HIP(hipGetLastError());
-      PQ_HIP(hipStreamSynchronize(c->stream));  // h32 goes out of scope
-    }
-    if (T > 0) {
-      // tufted cover: two faces per triangle, glued around every edge
-      hipLaunchKernelGGL(k_cover_init, gt, blk, 0, c->stream, T, d_tris, d_len, d_eps, d_eps_tri, d_fv, d_fl,
-                         d_bcount);
-      PQ_TRY(exclusive_scan_i32(c, d_bcount, n + 1));
-      hipLaunchKernelGGL(k_edge_scatter, gt, blk, 0, c->stream, T, d_tris, d_bcount, d_bcursor,
-                         d_rec);
-      hipLaunchKernelGGL(k_glue, gn, blk, 0, c->stream, N, d_bcount, d_rec, d_fn);
-      PQ_HIP(hipGetLastError());
-      // intrinsic Delaunay flips: rounds of conflict-free flips until none is left
-      ProfScope pf(c, "lap_flips");
-      PQ_HIP(hipMemsetAsync(d_claim, 0, (size_t(F) + 1) * 8, c->stream));
-      PQ_HIP(hipMemsetAsync(d_mark, 0, (size_t(F) * 3 + 1) * 4, c->stream));
-      // counters: slot 0 = seeding pass, slot r + 1 = round r: {next list length, flips}
-      PQ_HIP(hipMemsetAsync(d_cnt, 0, size_t(kMaxFlipRounds + 2) * 8, c->stream));
-      hipLaunchKernelGGL(k_flip_seed, gh, blk, 0, c->stream, 3 * F, d_fl, d_fn, d_list[0], d_cnt);
-      int32_t hc[2] = {0, 0};
-      PQ_HIP(hipMemcpyAsync(hc, d_cnt, 8, hipMemcpyDeviceToHost, c->stream));
-      PQ_HIP(hipStreamSynchronize(c->stream));
-      int m = hc[0];  // last list length the host has seen (sizes the next launches)
-      int last_flips = -1, same_looks = 0;
-      for (int round = 0; round < kMaxFlipRounds && m > 0;) {
-        // a batch of rounds between two looks at the counters; the lists shrink fast, and a
-        // kernel whose list is longer than its grid covers simply strides
-        const dim3 gm(unsigned(std::min<int64_t>(ceil_div(m, 256), 4096)));
-        const int batch_end = std::min(round + kFlipBatch, kMaxFlipRounds);
-        for (; round < batch_end; ++round) {
-          const int32_t* cur = d_list[round & 1];
-          int32_t* nxt = d_list[(round & 1) ^ 1];
-          const unsigned long long stamp = (unsigned long long)(round + 1) << 32;
-          hipLaunchKernelGGL(k_flip_claim, gm, blk, 0, c->stream, d_cnt + 2 * round, cur, stamp, d_fl,
-                             d_fn, d_claim, d_iscand);
-          hipLaunchKernelGGL(k_flip_apply, gm, blk, 0, c->stream, d_cnt + 2 * round, cur, d_iscand, stamp,
-                             round, d_fv, d_fl, d_fn, d_claim, d_mark, nxt, d_cnt + 2 * (round + 1));
-        }
-        PQ_HIP(hipGetLastError());
-        PQ_HIP(hipMemcpyAsync(hc, d_cnt + 2 * round, 8, hipMemcpyDeviceToHost, c->stream));
-        PQ_HIP(hipStreamSynchronize(c->stream));
-        if (hc[1] == 0) break;  // the last round of the batch flipped nothing: done (or stuck)
-        // A handful of edges flipping back and forth for good: on nearly degenerate faces of
-        // a contracted cloud the rounding of the two cotangents can exceed the tolerance on
-        // both sides of a flip (seen: 2 flips a round from round 88 to the cap, 35 ms per
-        // build of a 50 k-point tree). The same few flips with the same list for
-        // kFlipCycleLooks looks in a row end the loop; either state of such an edge is as
-        // Delaunay as fp64 can tell.
-        if (hc[0] == m && hc[1] == last_flips && hc[1] <= kFlipCycleMax) {
-          if (++same_looks >= kFlipCycleLooks) break;
-        } else {
-          same_looks = 0;
-        }
-        last_flips = hc[1];
-        m = hc[0];
-        if (getenv("PYQSM_LBC_TRACE")) fprintf(stderr, "flip round %d list %d flips(last) %d\n", round, hc[0], hc[1]);
-      }
-      hipLaunchKernelGGL(k_cover_vcount, gf, blk, 0, c->stream, F, d_fv, d_vcount);
-    }
-    PQ_TRY(exclusive_scan_i32(c, d_vcount, n + 1));  // row_start of the contributions
-    if (T > 0) {
-      hipLaunchKernelGGL(k_cover_weights, gf, blk, 0, c->stream, F, d_fv, d_fl, d_vcount, d_cursor,
-                         d_ent, d_area);
-      PQ_HIP(hipGetLastError());
-    }
-    if (getenv("PYQSM_LBC_TRACE")) {  // longest row of contributions
-      std::vector<int32_t> rs(size_t(n) + 1);
-      PQ_HIP(hipMemcpyAsync(rs.data(), d_vcount, (size_t(n) + 1) * 4, hipMemcpyDeviceToHost, c->stream));
-      PQ_HIP(hipStreamSynchronize(c->stream));
-      int mx = 0;
-      int64_t over = 0;
-      for (int64_t i = 0; i < n; ++i) {
-        const int len = rs[size_t(i) + 1] - rs[size_t(i)];
-        mx = std::max(mx, len);
-        over += len > 64 * kSortPer;
-      }
-      fprintf(stderr, "laplacian rows: %d contributions at most, %lld rows beyond the wave path\n", mx,
-              (long long)over);
-    }
-    hipLaunchKernelGGL(k_sort_rows, dim3(ceil_div(n, 4)), blk, 0, c->stream, N, d_vcount, d_ent,
-                       d_nnzrow);
-    PQ_HIP(hipGetLastError());
-    PQ_TRY(exclusive_scan_i32(c, d_nnzrow, n + 1));  // indptr
-    int32_t nnz = 0;
-    PQ_HIP(hipMemcpyAsync(&nnz, d_nnzrow + n, 4, hipMemcpyDeviceToHost, c->stream));
-    PQ_HIP(hipStreamSynchronize(c->stream));
-    int32_t* d_indices;
-    double* d_vals;
-    PQ_TRY(c->arena.get(size_t(nnz) + 1, &d_indices));
-    PQ_TRY(c->arena.get(size_t(nnz) + 1, &d_vals));
-    hipLaunchKernelGGL(k_rows, gn, blk, 0, c->stream, N, d_vcount, d_ent, d_area, d_nnzrow, d_indices,
-                       d_vals, d_mass);
-    PQ_HIP(hipGetLastError());
+    LapOut lo;
+    PQ_TRY(laplacian_device(c, d_xyz, n, seg_start, n_seg, k, moll, &lo));
+    const int32_t nnz = lo.nnz;
+    int32_t *d_nnzrow = lo.indptr, *d_indices = lo.indices;
+    double *d_vals = lo.vals, *d_mass = lo.mass;
     int32_t* h_indices = static_cast<int32_t*>(out_alloc((size_t(nnz) + 1) * 4));
     double* h_vals = static_cast<double*>(out_alloc((size_t(nnz) + 1) * 8));
     if (!h_indices || !h_vals) {

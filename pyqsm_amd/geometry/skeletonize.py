@@ -161,7 +161,7 @@ def extract_skeleton(pcd, moll=_SK["moll"], n_neighbors=_SK["n_neighbors"],
                      max_attraction=_SK["max_attraction"],
                      step_wise_contraction_amplification=_SK["step_wise_contraction_amplification"],
                      cmag_save_file="", min_contraction=0, laplacian=None, device: int = 0,
-                     strict: bool = False):
+                     strict: bool = False, engine: str = "python"):
     """skeletonize.py:226-373. Returns ``(contracted, total_point_shift,
     shift_by_step)``: the contracted cloud (a PointCloud with ``.points``), the
     accumulated shift float64 [n,3] and the list of per-iteration shifts.
@@ -172,8 +172,30 @@ def extract_skeleton(pcd, moll=_SK["moll"], n_neighbors=_SK["n_neighbors"],
 
     The returned cloud carries ``solve_log``: one ``{"iters", "resid", "ok"}`` record per
     contraction solve (see :func:`least_squares_sparse`); ``strict=True`` makes a solve that
-    misses ``SOLVER_RTOL`` raise instead of feeding its best iterate to the next step."""
+    misses ``SOLVER_RTOL`` raise instead of feeding its best iterate to the next step.
+
+    ``engine="native"`` runs the same loop inside the library (``pyqsm_extract_skeleton``): the
+    points, the Laplacian and the weights stay in HBM between the steps instead of going through
+    NumPy / SciPy objects after every call. Same bookkeeping, same results up to the loop's own
+    run-to-run spread (tests/test_gpu_native_loop.py); ``laplacian=`` hooks, ``debug`` and the
+    shift pickles need the Python loop."""
     pts = as_points(pcd)
+    if engine == "native":
+        if laplacian is not None or debug or cmag_save_file:
+            raise ValueError("engine='native' does not take a laplacian hook, debug or cmag_save_file")
+        lo, hi = oriented_bounds(pts)                                      # :240-241
+        out, total, steps, n_steps, slog = hip.extract_skeleton(
+            pts, lo, hi, n_neighbors, moll, max_iter, termination_ratio, contraction_factor,
+            attraction_factor, max_contraction, max_attraction, SOLVER_RTOL, SOLVER_MAX_IT,
+            device=device)
+        if strict and not all(q["ok"] for q in slog):
+            raise ContractionSolveError("a contraction solve stopped before the error estimate "
+                                        f"reached {SOLVER_RTOL:.1e}")
+        contracted = PointCloud(out)
+        contracted.solve_log = slog
+        return contracted, total, [steps[t] for t in range(int(n_steps[0]))]
+    if engine != "python":
+        raise ValueError("engine must be 'python' or 'native'")
     solve_log = []
     allowed_range = oriented_bounds(pts)                               # :240-241
     lo, hi = np.asarray(allowed_range[0]), np.asarray(allowed_range[1])
@@ -256,6 +278,36 @@ def _pack_groups(sizes, group_points):
             groups.append([j])
             loads.append(sizes[j])
     return groups
+
+
+def _contract_group_native(clouds, moll, n_neighbors, max_iter, termination_ratio, contraction_factor,
+                           attraction_factor, max_contraction, max_attraction, device):
+    """:func:`_contract_group` inside the library: one ``pyqsm_extract_skeleton`` call with the
+    clouds as segments (same lattice layout, same per-cloud bookkeeping)."""
+    S = len(clouds)
+    pts = [np.array(as_points(c), dtype=np.float64) for c in clouds]
+    sizes = np.array([len(p) for p in pts])
+    start = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    ext = max(float((p.max(0) - p.min(0)).max()) for p in pts)
+    pitch = 2.0 * ext + 1.0
+    cols = int(np.ceil(np.sqrt(S)))
+    offs = np.array([[(j % cols) * pitch, (j // cols) * pitch, 0.0] for j in range(S)])
+    offs -= np.array([0.5 * (p.max(0) + p.min(0)) for p in pts])
+    bounds = [oriented_bounds(p) for p in pts]
+    lo = np.array([b[0] + o for b, o in zip(bounds, offs)])
+    hi = np.array([b[1] + o for b, o in zip(bounds, offs)])
+    cur = np.concatenate([p + o for p, o in zip(pts, offs)])
+    out, total, steps, n_steps, slog = hip.extract_skeleton(
+        cur, lo, hi, n_neighbors, moll, max_iter, termination_ratio, contraction_factor,
+        attraction_factor, max_contraction, max_attraction, SOLVER_RTOL, SOLVER_MAX_IT,
+        seg_start=start, device=device)
+    res = []
+    for j in range(S):
+        a, b = start[j], start[j + 1]
+        pc = PointCloud(out[a:b] - offs[j])
+        pc.solve_log = slog[: int(n_steps[j])]
+        res.append((pc, total[a:b].copy(), [steps[t, a:b].copy() for t in range(int(n_steps[j]))]))
+    return res
 
 
 def _contract_group(clouds, moll, n_neighbors, max_iter, termination_ratio, contraction_factor,
@@ -343,7 +395,7 @@ def extract_skeleton_batch(pcds, moll=_SK["moll"], n_neighbors=_SK["n_neighbors"
                            attraction_factor=_SK["init_attraction"],
                            max_contraction=_SK["max_contraction"],
                            max_attraction=_SK["max_attraction"], device: int = 0,
-                           group_points: int = 400_000, workers: int = 4):
+                           group_points: int = 400_000, workers: int = 4, engine: str = "python"):
     """``extract_skeleton`` for MANY clouds (the per-cluster calls of qsm_generation.py:182-316):
     returns one ``(contracted, total_point_shift, shift_by_step)`` triple per input cloud, in
     input order. Clouds are packed into groups of up to ``group_points`` points; a group is
@@ -361,8 +413,10 @@ def extract_skeleton_batch(pcds, moll=_SK["moll"], n_neighbors=_SK["n_neighbors"
     args = (moll, n_neighbors, max_iter, termination_ratio, contraction_factor, attraction_factor,
             max_contraction, max_attraction, device)
 
+    fn = _contract_group_native if engine == "native" else _contract_group
+
     def run(g):
-        return g, _contract_group([clouds[j] for j in g], *args)
+        return g, fn([clouds[j] for j in g], *args)
 
     results = [None] * len(clouds)
     with ThreadPoolExecutor(max_workers=max(1, int(workers))) as pool:

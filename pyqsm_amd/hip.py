@@ -440,3 +440,39 @@ def pc_laplacian(points, k: int = 30, moll: float = 1e-5, device: int = 0, seg_s
     indices = _adopt(lib, ix, ctypes.c_int32, max(nnz.value, 1), np.int32)[:nnz.value]
     data = _adopt(lib, dv, ctypes.c_double, max(nnz.value, 1), np.float64)[:nnz.value]
     return (indptr, indices, data), mass
+
+
+# ---------------------------------------------------------------- the whole contraction loop
+
+def extract_skeleton(points, lo, hi, k: int, moll: float, max_iter: int, termination_ratio: float,
+                     contraction_factor: float, attraction_factor: float, max_contraction: float,
+                     max_attraction: float, rtol: float, solver_max_it: int, seg_start=None,
+                     keep_steps: bool = True, device: int = 0):
+    """``pyqsm_extract_skeleton``: the loop of skeletonize.py:240-373 device-resident, for one
+    cloud or several stacked ones (``seg_start`` int64 [S+1]; ``lo`` / ``hi`` float64 [S,3]).
+    Returns ``(points [n,3], total_shift [n,3], steps [T,n,3] or None, n_steps int32 [S],
+    solve_log list of {"iters", "resid", "ok"})``."""
+    pts = _points(points)
+    n = pts.shape[0]
+    ss = (np.array([0, n], dtype=np.int64) if seg_start is None
+          else np.ascontiguousarray(seg_start, dtype=np.int64))
+    S = len(ss) - 1
+    lo = np.ascontiguousarray(np.asarray(lo, dtype=np.float64).reshape(S, 3))
+    hi = np.ascontiguousarray(np.asarray(hi, dtype=np.float64).reshape(S, 3))
+    T = max(int(max_iter), 1)
+    out = np.empty_like(pts)
+    total = np.empty_like(pts)
+    steps = np.empty((T, n, 3)) if keep_steps else None     # rows < n_solves are written by the library
+    n_steps = np.zeros(S, dtype=np.int32)
+    iters = np.zeros(T, dtype=np.int32)
+    resid = np.zeros(T)
+    ok = np.zeros(T, dtype=np.uint8)
+    n_solves = i32(0)
+    check(_lib.load().pyqsm_extract_skeleton(
+        _p(pts), n, _p(ss), S, int(k), float(moll), int(max_iter), float(termination_ratio),
+        float(contraction_factor), float(attraction_factor), float(max_contraction),
+        float(max_attraction), _p(lo), _p(hi), float(rtol), int(solver_max_it), _p(out), _p(total),
+        _p(steps), _p(n_steps), _p(iters), _p(resid), _p(ok), ctypes.byref(n_solves), int(device)))
+    log = [{"iters": int(iters[t]), "resid": [float(resid[t])] * 3, "ok": bool(ok[t])}
+           for t in range(n_solves.value)]
+    return out, total, steps, n_steps, log

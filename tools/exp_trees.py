@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--threads", type=int, default=8)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--batch", type=int, default=0, help="points per block-diagonal group (0: per-tree loop)")
+    ap.add_argument("--engine", default="python")
     a = ap.parse_args()
     if a.batch:
         from pyqsm_amd import _lib, synth
@@ -43,9 +44,9 @@ def main():
         clouds = [synth.forest(50_000, seed=s) for s in range(a.trees)]
         t0 = time.perf_counter()
         res = extract_skeleton_batch(clouds, max_iter=a.iters, termination_ratio=0.0,
-                                     group_points=a.batch, workers=a.threads)
+                                     group_points=a.batch, workers=a.threads, engine=a.engine)
         dt = time.perf_counter() - t0
-        print(f"trees={a.trees} batch={a.batch} threads={a.threads}: {dt:.2f} s = {dt / a.trees:.3f} s per tree "
+        print(f"trees={a.trees} batch={a.batch} threads={a.threads} engine={a.engine}: {dt:.2f} s = {dt / a.trees:.3f} s per tree "
               "(synthetic input excluded)", flush=True)
         return
     seeds = list(range(a.trees))
