@@ -509,7 +509,12 @@ int knn_device(Ctx* c, const double* xyz, int64_t n, int32_t k, int32_t exclude_
     PQ_TRY(cloud_bbox(c, xyz, n, box, box + 3));
     double ext = std::max(box[3] - box[0], std::max(box[4] - box[1], box[5] - box[2]));
     if (!(ext > 0)) ext = 1.0;
-    const double target = std::max(2.0, double(k) / 3.0);
+    static const double occ_div = [] {  // PYQSM_KNN_OCC: points per occupied cell = k / this
+      const char* e = getenv("PYQSM_KNN_OCC");
+      const double v = e ? atof(e) : 3.0;
+      return v > 0.25 && v < 64.0 ? v : 3.0;
+    }();
+    const double target = std::max(2.0, double(k) / occ_div);
     double c1, per1, c2, per2, dim = 2.0, cell;
     PQ_TRY(probe_occupancy(c, xyz, n, box, ext / 64.0, &c1, &per1));
     if (per1 <= 1.5 * target) {

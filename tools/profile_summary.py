@@ -25,6 +25,12 @@ def short(name):
     return name.split("(")[0].replace("void ", "")
 
 
+def plain(name):
+    """kernel name without namespace and template arguments: the key bench.py looks up"""
+    import re
+    return re.sub(r"<.*>$", "", name.replace("pyqsm::", ""))
+
+
 # 1. kernel stats of the whole default bench run
 rows = list(csv.DictReader(open(find("bench", "kernel_stats.csv"))))
 with open(f"{OUT}/{ROUND}_bench_kernel_stats.csv", "w") as f:
@@ -62,7 +68,7 @@ for k in fetch:
     if k in write and k.startswith("pyqsm::k_"):
         fk = sum(fetch[k]["FETCH_SIZE"]) / len(fetch[k]["FETCH_SIZE"])
         wk = sum(write[k]["WRITE_SIZE"]) / len(write[k]["WRITE_SIZE"])
-        kern[k.replace("pyqsm::", "")] = {"fetch_size_kib": fk, "write_size_kib": wk,
+        kern[plain(k)] = {"fetch_size_kib": fk, "write_size_kib": wk,
                                           "hbm_bytes_per_launch": (2.0 * fk + wk) * 1024.0}
 json.dump({"points": 1_000_000, "kernels": kern,
            "note": "hbm_bytes_per_launch = 2 x FETCH_SIZE + WRITE_SIZE (KiB x 1024) from separate rocprofv3 --pmc passes "
