@@ -66,3 +66,26 @@ def test_pack_groups():
     g = sk._pack_groups([50, 10, 40, 70, 30], 100)
     assert sorted(sum(g, [])) == [0, 1, 2, 3, 4]
     assert all(sum([50, 10, 40, 70, 30][j] for j in grp) <= 100 for grp in g)
+
+
+def test_stacked_laplacian_is_the_block_diagonal_of_the_per_cloud_ones(gpu):
+    """pyqsm_pc_laplacian_seg: clouds laid out apart give one block per cloud, each equal to the
+    cloud's own Laplacian (same neighbours, same fans, same flips, its OWN mollification length);
+    without seg_start the shared mollification length changes the values."""
+    from scipy.sparse import block_diag
+    clouds = [synth.forest(4000 + 700 * j, seed=60 + j) * (1.0 + 0.6 * j) + [40.0 * j, 0, 0] for j in range(3)]
+    P = np.concatenate(clouds)
+    start = np.concatenate([[0], np.cumsum([len(c) for c in clouds])])
+    L, M = sk.point_cloud_laplacian(P, mollify_factor=1e-3, n_neighbors=20, device=gpu, seg_start=start)
+    parts = [sk.point_cloud_laplacian(c, mollify_factor=1e-3, n_neighbors=20, device=gpu) for c in clouds]
+    want = block_diag([q[0] for q in parts], format="csr")
+    want.sort_indices()
+    assert np.array_equal(L.indptr, want.indptr) and np.array_equal(L.indices, want.indices)
+    scale = np.abs(want.data).max()
+    assert np.abs(L.data - want.data).max() <= 1e-12 * scale
+    mass = np.concatenate([q[1].diagonal() for q in parts])
+    assert np.abs(M.diagonal() - mass).max() <= 1e-12 * mass.max()
+    # one global mollification length instead (no seg_start) is a different matrix (other edge
+    # lengths, other flips)
+    L1, _ = sk.point_cloud_laplacian(P, mollify_factor=1e-3, n_neighbors=20, device=gpu)
+    assert L1.nnz != want.nnz or np.abs(L1.data - want.data).max() > 1e-9 * scale
