@@ -142,6 +142,10 @@ int pyqsm_cast_rays_multi(const float* verts, int64_t V, const int32_t* tris, in
                           const float* rays, int64_t R,
                           float* t_hit, uint32_t* prim_id, float* uv, int32_t n_devices);
 
+/* The contiguous shard [*begin, *end) of `rank` among `world` ranks over n items, as
+ * pyqsm_cast_rays_multi splits the rays (sizes differ by at most one, in rank order; needs no GPU). */
+int pyqsm_shard_bounds(int64_t n, int32_t world, int32_t rank, int64_t* begin, int64_t* end);
+
 /*
  * One process PER GPU (torchrun-style launches): a communicator per process and the
  * data-path collectives on the library stream of the rank's device. Rank 0 creates the

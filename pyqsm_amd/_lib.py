@@ -39,6 +39,7 @@ SIGNATURES = {
                                                 i64, ctypes.POINTER(i64), i32]),
     "pyqsm_point_mesh_distance": (ctypes.c_int, [vp, i64, vp, i64, vp, i64, vp, vp, i32]),
     "pyqsm_cast_rays_multi": (ctypes.c_int, [vp, i64, vp, i64, vp, i64, vp, vp, vp, i32]),
+    "pyqsm_shard_bounds": (ctypes.c_int, [i64, i32, i32, ctypes.POINTER(i64), ctypes.POINTER(i64)]),
     "pyqsm_comm_unique_id": (ctypes.c_int, [vp]),
     "pyqsm_comm_init_rank": (ctypes.c_int, [vp, i32, i32, i32]),
     "pyqsm_comm_finalize": (ctypes.c_int, []),

@@ -223,6 +223,13 @@ int pyqsm_cast_rays_multi(const float* verts, int64_t V, const int32_t* tris, in
   return 0;
 }
 
+int pyqsm_shard_bounds(int64_t n, int32_t world, int32_t rank, int64_t* begin, int64_t* end) {
+  if (n < 0 || world < 1 || rank < 0 || rank >= world || !begin || !end)
+    return fail(PYQSM_EINVAL, "pyqsm_shard_bounds: bad argument");
+  shard(n, world, rank, begin, end);
+  return 0;
+}
+
 /* ---- one process per GPU ------------------------------------------------------------- */
 
 int pyqsm_comm_unique_id(uint8_t* id) {

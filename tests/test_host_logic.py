@@ -262,3 +262,23 @@ def test_select_by_index_is_by_vertex_like_open3d():
     assert len(sel.triangles) == 4 and abs(sel.get_surface_area() - 2.0) < 1e-12
     assert abs(m.select_by_triangle(hit).get_surface_area() - 1.0) < 1e-12
     assert np.array_equal(sel.vertices, v[verts])
+
+
+def test_library_and_python_shard_the_same_way():
+    """pyqsm_cast_rays_multi (C) and parallel.shard_bounds (Python, used by the one-process-per-GPU
+    path and by bench.py) must cut the rays at the same places: results are placed by these bounds."""
+    import ctypes
+    from pyqsm_amd import _lib
+    lib = _lib.load()
+    for n in (0, 1, 7, 8, 9, 1001, 10_000_000, 2**33 + 5):
+        for world in (1, 2, 3, 4, 8):
+            prev = 0
+            for rank in range(world):
+                b, e = ctypes.c_int64(-1), ctypes.c_int64(-1)
+                assert lib.pyqsm_shard_bounds(n, world, rank, ctypes.byref(b), ctypes.byref(e)) == 0
+                assert (b.value, e.value) == shard_bounds(n, world, rank)
+                assert b.value == prev
+                prev = e.value
+            assert prev == n
+    b, e = ctypes.c_int64(0), ctypes.c_int64(0)
+    assert lib.pyqsm_shard_bounds(10, 2, 2, ctypes.byref(b), ctypes.byref(e)) == -1
