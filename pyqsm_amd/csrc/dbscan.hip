@@ -346,8 +346,10 @@ static constexpr int kSubPerWaveDefault = 4;
 // Full path compression for the listed representatives (plain accesses: the kernel
 // boundary makes the unions of the previous launch visible, and any value another lane
 // writes meanwhile is an ancestor too).
-__global__ __launch_bounds__(256) void k_flatten_reps(const int4* __restrict__ list, int m,
+__global__ __launch_bounds__(256) void k_flatten_reps(const int4* __restrict__ list,
+                                                      const int32_t* __restrict__ m_ptr,
                                                       int* __restrict__ parent) {
+  const int m = *m_ptr;  // number of listed sub-cells, left on the device by k_sub_rep
   int s = blockIdx.x * 256 + threadIdx.x;
   if (s >= m) return;
   const int p = list[s].x;
@@ -363,7 +365,8 @@ __global__ __launch_bounds__(256) void k_flatten_reps(const int4* __restrict__ l
 // chasing), and what remains after compression is a few trees per cluster — one per
 // sub-cell without a connected smaller neighbour. One wave per sub-cell as below.
 template <int kSubPerWave>
-__global__ __launch_bounds__(256) void k_hook_sub(const int4* __restrict__ list, int m, int nx,
+__global__ __launch_bounds__(256) void k_hook_sub(const int4* __restrict__ list,
+                                                  const int32_t* __restrict__ m_ptr, int nx,
                                                   int ny, const int32_t* __restrict__ start,
                                                   const int4* __restrict__ rec,
                                                   const double* __restrict__ sx,
@@ -372,6 +375,7 @@ __global__ __launch_bounds__(256) void k_hook_sub(const int4* __restrict__ list,
                                                   const uint8_t* __restrict__ core,
                                                   int* __restrict__ parent,
                                                   int32_t* __restrict__ nbr) {
+  const int m = *m_ptr;
   const int s0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * kSubPerWave;
   if (s0 >= m) return;  // wave-uniform
   const int k = threadIdx.x & 63;
@@ -457,7 +461,8 @@ __global__ __launch_bounds__(256) void k_hook_sub(const int4* __restrict__ list,
 // running the pair loop itself was 3x slower: ~25 dependent iterations per lane, and a wave
 // lasts as long as its slowest lane.)
 template <int kSubPerWave>
-__global__ __launch_bounds__(256) void k_union_sub(const int4* __restrict__ list, int m,
+__global__ __launch_bounds__(256) void k_union_sub(const int4* __restrict__ list,
+                                                   const int32_t* __restrict__ m_ptr,
                                                    const int32_t* __restrict__ nbr,
                                                    const int32_t* __restrict__ sub_of,
                                                    const int4* __restrict__ rec,
@@ -465,6 +470,7 @@ __global__ __launch_bounds__(256) void k_union_sub(const int4* __restrict__ list
                                                    const double* __restrict__ sy,
                                                    const double* __restrict__ sz, double r2,
                                                    const uint8_t* __restrict__ core, int* parent) {
+  const int m = *m_ptr;
   const int s0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * kSubPerWave;
   if (s0 >= m) return;  // wave-uniform
   const int k = threadIdx.x & 63;
@@ -562,10 +568,12 @@ __global__ __launch_bounds__(256) void k_point_min(int n, const uint8_t* __restr
 // wave's representatives share a root (the common case), and an atomic only if it can
 // still lower the stored minimum. (Folding all core points this way cost 0.23 ms per
 // million points: atomics and coherent loads on a handful of hot addresses.)
-__global__ __launch_bounds__(256) void k_rep_min(const int4* __restrict__ list, int m,
+__global__ __launch_bounds__(256) void k_rep_min(const int4* __restrict__ list,
+                                                 const int32_t* __restrict__ m_ptr,
                                                  const int* __restrict__ parent,
                                                  const int* __restrict__ run_min,
                                                  int* __restrict__ min_orig) {
+  const int m = *m_ptr;
   int s = blockIdx.x * 256 + threadIdx.x;
   const bool active = s < m;
   int r = -1, v = 0x7FFFFFFF;
@@ -768,47 +776,37 @@ static int dbscan_device(Ctx* c, const double* xyz, int64_t n, double eps, int32
     if (fine) {
       hipLaunchKernelGGL(k_sub_rep, dim3(ceil_div(n, 1024)), dim3(1024), 0, c->stream, N, sub.sub_of, sub.sub_beg, sub.sub_cnt,
                          core, g.order, parent, g.cell_of, sub.rec, run_min, list, list_cnt);
-      int32_t m = 0;
-      PQ_HIP(hipMemcpyAsync(&m, list_cnt, 4, hipMemcpyDeviceToHost, c->stream));
-      PQ_HIP(hipStreamSynchronize(c->stream));
-      if (m > 0) {
-        static const int spw = [] {  // PYQSM_SUB_PER_WAVE: sub-cells one wave takes (2, 4 or 8)
-          const char* e = getenv("PYQSM_SUB_PER_WAVE");
-          const int v = e ? atoi(e) : kSubPerWaveDefault;
-          return (v == 2 || v == 8) ? v : 4;
-        }();
-        const dim3 gw(ceil_div(m, 4 * spw)), gl(ceil_div(m, 256));
+      // The number m of listed sub-cells stays on the device: the passes below are launched for the
+      // upper bound (a sub-cell holds at least one point, in practice ~5) and read m themselves —
+      // waves beyond it leave at once — which spares the host round trip in the middle of the step
+      // (~15 us of an 0.7 ms step). Clouds so large that the neighbour table for n rows would not be
+      // reasonable (> 8 GiB) read m back and size everything exactly.
+      int64_t rows = n;
+      if (size_t(n) * 256 > (size_t(8) << 30)) {
+        int32_t m = 0;
+        PQ_HIP(hipMemcpyAsync(&m, list_cnt, 4, hipMemcpyDeviceToHost, c->stream));
+        PQ_HIP(hipStreamSynchronize(c->stream));
+        rows = m;
+      }
+      if (rows > 0) {
+        const dim3 gw(ceil_div(rows, 4 * kSubPerWaveDefault)), gl(ceil_div(rows, 256));
         int32_t* nbr;  // [m][64] representatives of the neighbour sub-cells pass 1 resolved
-        PQ_TRY(c->arena.get(size_t(m) * 64, &nbr));
+        PQ_TRY(c->arena.get(size_t(rows) * 64, &nbr));
         {
           ProfScope pk(c, "k_hook_sub");
-          if (spw == 2)
-            hipLaunchKernelGGL(k_hook_sub<2>, gw, block, 0, c->stream, list, m, g.nx, g.ny, g.start, sub.rec,
-                               g.sx, g.sy, g.sz, r2, core, parent, nbr);
-          else if (spw == 8)
-            hipLaunchKernelGGL(k_hook_sub<8>, gw, block, 0, c->stream, list, m, g.nx, g.ny, g.start, sub.rec,
-                               g.sx, g.sy, g.sz, r2, core, parent, nbr);
-          else
-            hipLaunchKernelGGL(k_hook_sub<4>, gw, block, 0, c->stream, list, m, g.nx, g.ny, g.start, sub.rec,
-                               g.sx, g.sy, g.sz, r2, core, parent, nbr);
+          hipLaunchKernelGGL(k_hook_sub<kSubPerWaveDefault>, gw, block, 0, c->stream, list, list_cnt, g.nx, g.ny, g.start, sub.rec,
+                             g.sx, g.sy, g.sz, r2, core, parent, nbr);
         }
-        hipLaunchKernelGGL(k_flatten_reps, gl, block, 0, c->stream, list, m, parent);
+        hipLaunchKernelGGL(k_flatten_reps, gl, block, 0, c->stream, list, list_cnt, parent);
         // what is left: joining the few trees per cluster. Almost every pair of neighbours
         // now shows the same root through two plain loads.
         {
           ProfScope pk(c, "k_union_sub");
-          if (spw == 2)
-            hipLaunchKernelGGL(k_union_sub<2>, gw, block, 0, c->stream, list, m, nbr, sub.sub_of, sub.rec,
-                               g.sx, g.sy, g.sz, r2, core, parent);
-          else if (spw == 8)
-            hipLaunchKernelGGL(k_union_sub<8>, gw, block, 0, c->stream, list, m, nbr, sub.sub_of, sub.rec,
-                               g.sx, g.sy, g.sz, r2, core, parent);
-          else
-            hipLaunchKernelGGL(k_union_sub<4>, gw, block, 0, c->stream, list, m, nbr, sub.sub_of, sub.rec,
-                               g.sx, g.sy, g.sz, r2, core, parent);
+          hipLaunchKernelGGL(k_union_sub<kSubPerWaveDefault>, gw, block, 0, c->stream, list, list_cnt, nbr, sub.sub_of, sub.rec,
+                             g.sx, g.sy, g.sz, r2, core, parent);
         }
-        hipLaunchKernelGGL(k_flatten_reps, gl, block, 0, c->stream, list, m, parent);
-        hipLaunchKernelGGL(k_rep_min, gl, block, 0, c->stream, list, m, parent, run_min, min_orig);
+        hipLaunchKernelGGL(k_flatten_reps, gl, block, 0, c->stream, list, list_cnt, parent);
+        hipLaunchKernelGGL(k_rep_min, gl, block, 0, c->stream, list, list_cnt, parent, run_min, min_orig);
       }
       PQ_HIP(hipGetLastError());
       hipLaunchKernelGGL(k_flatten, grid, block, 0, c->stream, N, core, parent, min_orig, flag);
