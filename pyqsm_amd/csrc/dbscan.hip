@@ -579,7 +579,10 @@ __global__ __launch_bounds__(256) void k_rep_min(const int4* __restrict__ list,
   int r = -1, v = 0x7FFFFFFF;
   if (active) {
     const int p = list[s].x;
-    r = parent[p];  // k_flatten_reps ran: the root
+    // the root: after the compression that preceded k_union_sub and its few unions the chain is
+    // one to three links long (a second compression pass over the list cost 20 us for this)
+    r = p;
+    for (int nx = parent[r]; nx != r; nx = parent[r]) r = nx;
     v = run_min[p];
   }
   const volatile int* vmin = min_orig;  // plain pre-check: a stale value only costs an atomic
@@ -805,7 +808,6 @@ static int dbscan_device(Ctx* c, const double* xyz, int64_t n, double eps, int32
           hipLaunchKernelGGL(k_union_sub<kSubPerWaveDefault>, gw, block, 0, c->stream, list, list_cnt, nbr, sub.sub_of, sub.rec,
                              g.sx, g.sy, g.sz, r2, core, parent);
         }
-        hipLaunchKernelGGL(k_flatten_reps, gl, block, 0, c->stream, list, list_cnt, parent);
         hipLaunchKernelGGL(k_rep_min, gl, block, 0, c->stream, list, list_cnt, parent, run_min, min_orig);
       }
       PQ_HIP(hipGetLastError());
