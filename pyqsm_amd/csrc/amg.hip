@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void k_diag_l1(int n, const int32_t* __restric
                                                  const int32_t* __restrict__ indices,
                                                  const double* __restrict__ vals,
                                                  double* __restrict__ diag,
-                                                 double* __restrict__ dinv) {
+                                                 double* __restrict__ dinv, double omega) {
   int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   double s = 0.0, d = 0.0;
@@ -97,7 +97,12 @@ __global__ __launch_bounds__(256) void k_diag_l1(int n, const int32_t* __restric
     if (indices[j] == i) d = vals[j];
   }
   diag[i] = d;
-  dinv[i] = s > 0.0 ? 1.0 / s : 1.0;
+  // omega = 0: l1-Jacobi, 1 / sum |a_ij| (for these diagonally dominant M-matrices about half of
+  // 1 / a_ii); omega > 0: damped Jacobi, omega / a_ii, never above the l1 bound times two
+  if (omega > 0.0 && d > 0.0)
+    dinv[i] = omega / d;
+  else
+    dinv[i] = s > 0.0 ? 1.0 / s : 1.0;
 }
 
 // B = diag(cw) L + diag(wh) as an explicit CSR copy (same pattern as L: L stores its diagonal);
@@ -830,6 +835,15 @@ static int aggregate(Ctx* c, AmgLevel& F, int32_t* d_counter, int* nc_out) {
   return 0;
 }
 
+static double smoother_omega() {  // PYQSM_AMG_OMEGA: damped-Jacobi weight of the smoother (0 = l1-Jacobi)
+  static const double v = [] {
+    const char* e = getenv("PYQSM_AMG_OMEGA");
+    const double w = e ? atof(e) : 0.0;
+    return w > 0.0 && w < 1.0 ? w : 0.0;
+  }();
+  return v;
+}
+
 int amg_build(Ctx* c, const DevCsr& Lm, int n, const double* cw, const double* wh, AmgHierarchy** out) {
   *out = nullptr;
   AmgHierarchy* H = new AmgHierarchy();
@@ -862,7 +876,7 @@ int amg_build(Ctx* c, const DevCsr& Lm, int n, const double* cw, const double* w
   hipLaunchKernelGGL(k_make_b, dim3(ceil_div(n, 256)), dim3(256), 0, c->stream, n, Lm.indptr,
                      Lm.indices, Lm.vals, cw, wh, l0.A.vals);
   hipLaunchKernelGGL(k_diag_l1, dim3(ceil_div(n, 256)), dim3(256), 0, c->stream, n, l0.A.indptr,
-                     l0.A.indices, l0.A.vals, l0.diag, l0.dinv);
+                     l0.A.indices, l0.A.vals, l0.diag, l0.dinv, smoother_omega());
   AMG_TRY(alloc_vectors(c, l0, false, nnz0));
   l0.nnz = nnz0;
   H->lv.push_back(l0);
@@ -907,7 +921,7 @@ int amg_build(Ctx* c, const DevCsr& Lm, int n, const double* cw, const double* w
     AMG_TRY(c->arena.get(size_t(nc), &C.diag));
     AMG_TRY(c->arena.get(size_t(nc), &C.dinv));
     hipLaunchKernelGGL(k_diag_l1, gc, blk, 0, c->stream, nc, C.A.indptr, C.A.indices, C.A.vals, C.diag,
-                       C.dinv);
+                       C.dinv, smoother_omega());
     AMG_HIP(hipGetLastError());
     AMG_TRY(alloc_vectors(c, C, true, h2[0]));
     C.nnz = h2[0];
