@@ -70,7 +70,14 @@ for k in fetch:
         wk = sum(write[k]["WRITE_SIZE"]) / len(write[k]["WRITE_SIZE"])
         kern[plain(k)] = {"fetch_size_kib": fk, "write_size_kib": wk,
                                           "hbm_bytes_per_launch": (2.0 * fk + wk) * 1024.0}
-json.dump({"points": 1_000_000, "kernels": kern,
+calibration = {}
+if "k_bbox" in kern and "k_union_init" in kern:
+    calibration = {
+        "k_bbox (reads the 24 B/point AoS cloud once, 8-byte loads at a 24-byte stride)":
+            {"actual_read_bytes": 24.0e6, "FETCH_SIZE_bytes": kern["k_bbox"]["fetch_size_kib"] * 1024},
+        "k_union_init (writes three int32 arrays of n)":
+            {"actual_write_bytes": 12.0e6 + 4, "WRITE_SIZE_bytes": kern["k_union_init"]["write_size_kib"] * 1024}}
+json.dump({"points": 1_000_000, "kernels": kern, "calibration": calibration,
            "note": "hbm_bytes_per_launch = 2 x FETCH_SIZE + WRITE_SIZE (KiB x 1024) from separate rocprofv3 --pmc passes "
                    f"(profiles/{ROUND}_dbscan_pmc_*.csv). gfx950 FETCH_SIZE reports half the bytes read "
                    "(MI355X_MICROARCH.md); calibrated on this code's own access patterns: k_bbox reads exactly 24 B per "
