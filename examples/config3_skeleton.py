@@ -29,12 +29,14 @@ def main():
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--engine", default="python", help="python (loop over the C-ABI calls) or native "
                                                          "(pyqsm_extract_skeleton: the whole loop in HBM)")
+    ap.add_argument("--prof-level", type=int, default=1,
+                    help="2: also time the level-0 sparse passes one by one (no graphs, slower)")
     args = ap.parse_args()
     if args.verbose:
         logging.basicConfig(level=logging.INFO)
     _lib.require_gpu(0)
     pts = synth.forest(args.points, seed=0)
-    hip.prof_enable(True)
+    hip.prof_enable(args.prof_level)
     hip.prof_reset()
     t0 = time.perf_counter()
     got, total, steps = sk.extract_skeleton(pts, max_iter=args.iters, termination_ratio=0.0,
@@ -56,6 +58,10 @@ def main():
            "solve_outer_iterations": prof["lbc_outer_iter"][1],
            "solve_outer_ms_incl_inner": prof["lbc_outer_iter"][0],
            "mean_shift_m": float(np.linalg.norm(total, axis=1).mean())}
+    if args.prof_level >= 2:
+        for k in ("k_bspmv_f", "k_down_l0", "k_up_l0"):
+            ms, cnt = hip.prof_get(k)
+            out[k + "_us"] = 1e3 * ms / max(cnt, 1)
     print(json.dumps(out))
 
 

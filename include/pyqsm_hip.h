@@ -356,6 +356,18 @@ int pyqsm_extract_skeleton(const double* xyz, int64_t n, const int64_t* seg_star
                            int32_t* solve_iters, double* solve_resid, uint8_t* solve_ok,
                            int32_t* n_solves, int32_t device);
 
+/*
+ * Host-side helper of that loop, exported so that it can be checked without a GPU: the mean of
+ * v[0..n) with NumPy's summation order (pairwise in blocks of 128 with eight accumulators, one
+ * 8192-element buffer after the other, as np.add.reduce runs over a contiguous array with the
+ * default buffer size), i.e. bit for bit what np.mean(M.diagonal())
+ * of pyQSM/geometry/skeletonize.py:265,349 returns. The initial Laplacian weight is
+ * 10^3 c sqrt(mean M): one ulp of difference there is amplified by the loop to millimetres
+ * after twenty steps, so the native loop takes the mean the way the Python loop gets it.
+ * n <= 0: *out = NaN.
+ */
+int pyqsm_mean_f64(const double* v, int64_t n, double* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -73,6 +73,7 @@ SIGNATURES = {
     "pyqsm_pc_laplacian_seg": (ctypes.c_int, [vp, i64, vp, i64, i32, dbl, ctypes.POINTER(i64),
                                               ctypes.POINTER(vp), ctypes.POINTER(vp),
                                               ctypes.POINTER(vp), vp, i32]),
+    "pyqsm_mean_f64": (ctypes.c_int, [vp, i64, ctypes.POINTER(dbl)]),
 }
 
 _lib = None

@@ -530,9 +530,9 @@ __global__ __launch_bounds__(256) void k_up(int n, const int32_t* __restrict__ i
                                             const float* __restrict__ b,
                                             const float* __restrict__ x, TO* __restrict__ out,
                                             const TBD* __restrict__ bd /*may be null*/,
-                                            double* __restrict__ dot /*may be null*/) {
+                                            double* __restrict__ dot /*[3][kPart], may be null*/) {
   double d0 = 0.0, d1 = 0.0, d2 = 0.0;
-  // grid-stride: with a dot product the launch is capped (the atomics that end it are per block)
+  // grid-stride: with a dot product the launch is reduce_grid (one partial slot per block)
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
     const int e = indptr[i + 1];
@@ -585,7 +585,7 @@ __global__ __launch_bounds__(256) void k_up(int n, const int32_t* __restrict__ i
       d2 += double(e2) * double(o2);
     }
   }
-  if (dot) reduce3_atomic(d0, d1, d2, dot);
+  if (dot) reduce3_part(d0, d1, d2, dot);
 }
 
 // The same upward step through A P (see AmgLevel::ap_ptr): with x = Dinv b and r = b - A x from
@@ -600,7 +600,7 @@ __global__ __launch_bounds__(256) void k_up_ap(int n, const int32_t* __restrict_
                                                const float* __restrict__ r,
                                                const float* __restrict__ x, TO* __restrict__ out,
                                                const TBD* __restrict__ bd /*may be null*/,
-                                               double* __restrict__ dot /*may be null*/) {
+                                               double* __restrict__ dot /*[3][kPart], may be null*/) {
   double d0 = 0.0, d1 = 0.0, d2 = 0.0;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
@@ -645,7 +645,7 @@ __global__ __launch_bounds__(256) void k_up_ap(int n, const int32_t* __restrict_
       d2 += double(e2) * double(o2);
     }
   }
-  if (dot) reduce3_atomic(d0, d1, d2, dot);
+  if (dot) reduce3_part(d0, d1, d2, dot);
 }
 
 // one l1-Jacobi sweep out = x + Dinv (b - A x)   (coarsest level without a dense inverse)
@@ -1020,7 +1020,7 @@ static int vcycle_impl(Ctx* c, AmgHierarchy* H, const TV* b, TV* x, double* dot)
     ProfScope pk(c, l == 0 ? "k_up_l0" : "k_up_coarse", 1, 2);
     if (L.ap_ptr) {
       if (l == 0)
-        hipLaunchKernelGGL((k_up_ap<TV, TV>), dot ? dim3(std::min<int64_t>(ceil_div(L.n, 256), 1024)) : g, blk, 0,
+        hipLaunchKernelGGL((k_up_ap<TV, TV>), dot ? dim3(reduce_grid(L.n)) : g, blk, 0,
                            c->stream, L.n, L.ap_ptr, L.ap_idx, L.ap_val, L.dinvf, L.agg, C.xb, L.r, L.xa, x,
                            dot ? b : static_cast<const TV*>(nullptr), dot);
       else
@@ -1030,7 +1030,7 @@ static int vcycle_impl(Ctx* c, AmgHierarchy* H, const TV* b, TV* x, double* dot)
       continue;
     }
     if (l == 0)
-      hipLaunchKernelGGL((k_up<TV, TV>), dot ? dim3(std::min<int64_t>(ceil_div(L.n, 256), 1024)) : g, blk, 0,
+      hipLaunchKernelGGL((k_up<TV, TV>), dot ? dim3(reduce_grid(L.n)) : g, blk, 0,
                          c->stream, L.n, L.A.indptr, L.A.indices, L.valsf,
                          L.dinvf, L.agg, L.aggcol, C.xb, b0, L.xa, x, dot ? b : static_cast<const TV*>(nullptr), dot);
     else

@@ -138,4 +138,9 @@ int laplacian_device(Ctx* c, const double* d_xyz, int64_t n, const int64_t* seg_
 // Exclusive prefix sum of n int32 values, in place, on the stream (scan.hip).
 int exclusive_scan_i32(Ctx* c, int32_t* data, int64_t n);
 
+// Stable sort of n (key, value) pairs by the low `bits` bits of the key (scan.hip: radix passes
+// without global atomics, so the order is reproducible). *keys / *vals are the inputs and, on
+// return, point at the sorted arrays (the inputs themselves or arena buffers of the same size).
+int stable_sort_pairs_u32(Ctx* c, uint32_t** keys, int32_t** vals, int64_t n, int bits);
+
 }  // namespace pyqsm

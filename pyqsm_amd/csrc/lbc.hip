@@ -90,12 +90,12 @@ __global__ __launch_bounds__(256) void k_diag(int n, const int32_t* __restrict__
   minv[i] = d > 0.0 ? 1.0 / d : 1.0;
 }
 
-// Scalars of the fused Jacobi-PCG, kept on the device. Two slots alternate with
-// the iteration parity p: rz[p] is the current r.z, rz[p^1] collects the next one;
-// each kernel clears the slot that the following kernels will accumulate into, so
-// an iteration is four launches with no separate bookkeeping kernel.
+// Scalars of the fused CG loops, kept on the device as partial arrays (sparse.hpp:
+// reduce3_part / part_total3 — no atomics, reproducible bits). Two slots alternate with the
+// iteration parity p: rz[p] is the current r.z, rz[p^1] receives the next one; a producer
+// overwrites its array completely, so an iteration is four launches with no bookkeeping kernel.
 struct Scal {
-  double rz[2][3], pq[2][3], rr[2][3], bb[3];
+  double rz[2][3 * kPart], pq[2][3 * kPart], rr[2][3 * kPart], bb[3 * kPart];
 };
 
 enum Op { OP_A = 0, OP_B = 1 };  // A = wl L L wl + wh^2 ; B = wl L + wh (wl constant along the edges of L)
@@ -106,9 +106,8 @@ __global__ __launch_bounds__(256) void k_init(int n, const double* __restrict__ 
                                               const double* __restrict__ minv,
                                               double* __restrict__ r, double* __restrict__ dir,
                                               Scal* __restrict__ sc) {
-  int i = blockIdx.x * 256 + threadIdx.x;
   double rz[3] = {0, 0, 0}, rr[3] = {0, 0, 0}, bb[3] = {0, 0, 0};
-  if (i < n) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {  // reduce_grid
     const double mi = minv[i];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -117,16 +116,16 @@ __global__ __launch_bounds__(256) void k_init(int n, const double* __restrict__ 
       const double zi = mi * ri;
       r[3 * i + k] = ri;
       dir[3 * i + k] = zi;
-      rz[k] = ri * zi;
-      rr[k] = ri * ri;
-      bb[k] = bi * bi;
+      rz[k] += ri * zi;
+      rr[k] += ri * ri;
+      bb[k] += bi * bi;
     }
   }
-  reduce3_atomic(rz[0], rz[1], rz[2], sc->rz[0]);
+  reduce3_part(rz[0], rz[1], rz[2], sc->rz[0]);
   __syncthreads();
-  reduce3_atomic(rr[0], rr[1], rr[2], sc->rr[1]);
+  reduce3_part(rr[0], rr[1], rr[2], sc->rr[1]);
   __syncthreads();
-  reduce3_atomic(bb[0], bb[1], bb[2], sc->bb);
+  reduce3_part(bb[0], bb[1], bb[2], sc->bb);
 }
 
 // Sparse pass fused with the operator tail: t = L v for row i, then
@@ -143,10 +142,8 @@ __global__ __launch_bounds__(256) void k_spmv3_tail(int n, const int32_t* __rest
                                                     const double* __restrict__ dirv,
                                                     double* __restrict__ q, Scal* __restrict__ sc,
                                                     int par) {
-  int i = blockIdx.x * 256 + threadIdx.x;
   double pq[3] = {0, 0, 0};
-  if (sc && i < 3) sc->rz[par ^ 1][i] = 0.0;
-  if (i < n) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {  // reduce_grid when sc
     double a0 = 0.0, a1 = 0.0, a2 = 0.0;
     const int b = indptr[i], e = indptr[i + 1];
     for (int j = b; j < e; j += kRowChunk) {
@@ -179,10 +176,10 @@ __global__ __launch_bounds__(256) void k_spmv3_tail(int n, const int32_t* __rest
       const double d = dirv[3 * i + k];
       const double qi = a * t[k] + h * d;
       q[3 * i + k] = qi;
-      pq[k] = d * qi;
+      pq[k] += d * qi;
     }
   }
-  if (sc) reduce3_atomic(pq[0], pq[1], pq[2], sc->pq[par]);
+  if (sc) reduce3_part(pq[0], pq[1], pq[2], sc->pq[par]);
 }
 
 // alpha = rz/pq ; x += alpha dir ; r -= alpha q ; z = Minv r ; rz_new += r.z ; rr += r.r
@@ -192,26 +189,28 @@ __global__ __launch_bounds__(256) void k_update(int n, const double* __restrict_
                                                 double* __restrict__ x, double* __restrict__ r,
                                                 double* __restrict__ z, Scal* __restrict__ sc,
                                                 int par) {
-  int i = blockIdx.x * 256 + threadIdx.x;
-  double rz[3] = {0, 0, 0}, rr[3] = {0, 0, 0};
-  if (i < n) {
+  double rz[3] = {0, 0, 0}, rr[3] = {0, 0, 0}, pqt[3], rzt[3], alpha[3];
+  part_total3(sc->pq[par], pqt);
+  part_total3(sc->rz[par], rzt);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) alpha[k] = pqt[k] != 0.0 ? rzt[k] / pqt[k] : 0.0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {  // reduce_grid
     const double mi = minv[i];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      const double pqk = sc->pq[par][k];
-      const double alpha = pqk != 0.0 ? sc->rz[par][k] / pqk : 0.0;
-      x[3 * i + k] += alpha * dir[3 * i + k];
-      const double ri = r[3 * i + k] - alpha * q[3 * i + k];
+      x[3 * i + k] += alpha[k] * dir[3 * i + k];
+      const double ri = r[3 * i + k] - alpha[k] * q[3 * i + k];
       const double zi = mi * ri;
       r[3 * i + k] = ri;
       z[3 * i + k] = zi;
-      rz[k] = ri * zi;
-      rr[k] = ri * ri;
+      rz[k] += ri * zi;
+      rr[k] += ri * ri;
     }
   }
-  reduce3_atomic(rz[0], rz[1], rz[2], sc->rz[par ^ 1]);
   __syncthreads();
-  reduce3_atomic(rr[0], rr[1], rr[2], sc->rr[par]);
+  reduce3_part(rz[0], rz[1], rz[2], sc->rz[par ^ 1]);
+  __syncthreads();
+  reduce3_part(rr[0], rr[1], rr[2], sc->rr[par]);
 }
 
 // beta = rz_new/rz ; dir = z + beta dir
@@ -219,15 +218,13 @@ __global__ __launch_bounds__(256) void k_direction(int n, const double* __restri
                                                    double* __restrict__ dir,
                                                    Scal* __restrict__ sc, int par) {
   int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < 3) {  // slots the next iteration accumulates into
-    sc->pq[par ^ 1][i] = 0.0;
-    sc->rr[par ^ 1][i] = 0.0;
-  }
+  double rzo[3], rzn[3];
+  part_total3(sc->rz[par], rzo);
+  part_total3(sc->rz[par ^ 1], rzn);
   if (i >= n) return;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    const double rzk = sc->rz[par][k];
-    const double beta = rzk != 0.0 ? sc->rz[par ^ 1][k] / rzk : 0.0;
+    const double beta = rzo[k] != 0.0 ? rzn[k] / rzo[k] : 0.0;
     dir[3 * i + k] = z[3 * i + k] + beta * dir[3 * i + k];
   }
 }
@@ -256,13 +253,13 @@ struct S3 {
 
 __global__ __launch_bounds__(256) void k_dot3(int n, const double* __restrict__ a,
                                               const double* __restrict__ b,
-                                              double* __restrict__ out) {
+                                              double* __restrict__ out /*[3][kPart]*/) {
   double d[3] = {0, 0, 0};
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {  // capped grid
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {  // reduce_grid
 #pragma unroll
     for (int k = 0; k < 3; ++k) d[k] += a[3 * i + k] * b[3 * i + k];
   }
-  reduce3_atomic(d[0], d[1], d[2], out);
+  reduce3_part(d[0], d[1], d[2], out);
 }
 
 // y += s .* x (per column)
@@ -366,13 +363,14 @@ static int alloc_work(Ctx* c, int64_t n, Work* w) {
 static void apply_op(Ctx* c, const System& S, const Work& w, const double* v, double* q,
                      Scal* sc, int par = 0) {
   const dim3 grid(ceil_div(S.n, 256)), block(256);
+  const dim3 tgrid = sc ? dim3(reduce_grid(S.n)) : grid;
   if (S.op == OP_A) {
     hipLaunchKernelGGL(k_spmv3, grid, block, 0, c->stream, S.n, S.L.indptr, S.L.indices, S.L.vals,
                        S.wl, v, w.t1);
-    hipLaunchKernelGGL(k_spmv3_tail<OP_A>, grid, block, 0, c->stream, S.n, S.L.indptr, S.L.indices,
+    hipLaunchKernelGGL(k_spmv3_tail<OP_A>, tgrid, block, 0, c->stream, S.n, S.L.indptr, S.L.indices,
                        S.L.vals, w.t1, S.wl, S.wh, v, q, sc, par);
   } else {
-    hipLaunchKernelGGL(k_spmv3_tail<OP_B>, grid, block, 0, c->stream, S.n, S.L.indptr, S.L.indices,
+    hipLaunchKernelGGL(k_spmv3_tail<OP_B>, tgrid, block, 0, c->stream, S.n, S.L.indptr, S.L.indices,
                        S.L.vals, v, S.wl, S.wh, v, q, sc, par);
   }
 }
@@ -407,8 +405,8 @@ struct GraphCache {
 static void launch_iteration(Ctx* c, const System& S, const Work& w, double* x, int par) {
   const dim3 grid(ceil_div(S.n, 256)), block(256);
   apply_op(c, S, w, w.dir, w.q, w.sc, par);
-  hipLaunchKernelGGL(k_update, grid, block, 0, c->stream, S.n, w.dir, w.q, S.minv, x, w.r, w.z,
-                     w.sc, par);
+  hipLaunchKernelGGL(k_update, dim3(reduce_grid(S.n)), block, 0, c->stream, S.n, w.dir, w.q, S.minv, x,
+                     w.r, w.z, w.sc, par);
   hipLaunchKernelGGL(k_direction, grid, block, 0, c->stream, S.n, w.z, w.dir, w.sc, par);
 }
 
@@ -424,21 +422,24 @@ static int jacobi_pcg(Ctx* c, const System& S, const Work& w, const double* b, d
   PQ_HIP(hipMemsetAsync(w.sc, 0, sizeof(Scal), c->stream));
   if (zero_start) {
     PQ_HIP(hipMemsetAsync(x, 0, size_t(n) * 24, c->stream));
-    hipLaunchKernelGGL(k_init, grid, block, 0, c->stream, S.n, static_cast<const double*>(nullptr),
-                       b, S.minv, w.r, w.dir, w.sc);
+    hipLaunchKernelGGL(k_init, dim3(reduce_grid(n)), block, 0, c->stream, S.n,
+                       static_cast<const double*>(nullptr), b, S.minv, w.r, w.dir, w.sc);
   } else {
     apply_op(c, S, w, x, w.q, nullptr);
-    hipLaunchKernelGGL(k_init, grid, block, 0, c->stream, S.n, w.q, b, S.minv, w.r, w.dir, w.sc);
+    hipLaunchKernelGGL(k_init, dim3(reduce_grid(n)), block, 0, c->stream, S.n, w.q, b, S.minv, w.r,
+                       w.dir, w.sc);
   }
   PQ_HIP(hipGetLastError());
-  Scal h;
-  PQ_HIP(hipMemcpyAsync(&h, w.sc, sizeof(Scal), hipMemcpyDeviceToHost, c->stream));
-  PQ_HIP(hipStreamSynchronize(c->stream));
+  double h0[2][3];  // |r|^2, |b|^2
+  {
+    const double* parts[2] = {w.sc->rr[1], w.sc->bb};
+    PQ_TRY(part_totals_host(c, parts, 2, h0));
+  }
   double bnorm[3];
   bool done = true;
   for (int k = 0; k < 3; ++k) {
-    bnorm[k] = std::sqrt(h.bb[k]);
-    resid[k] = bnorm[k] > 0 ? std::sqrt(h.rr[1][k]) / bnorm[k] : 0.0;
+    bnorm[k] = std::sqrt(h0[1][k]);
+    resid[k] = bnorm[k] > 0 ? std::sqrt(h0[0][k]) / bnorm[k] : 0.0;
     if (resid[k] > rtol) done = false;
   }
   // Past the attainable accuracy (about cond * 1e-16) the recurrences drift and
@@ -479,8 +480,10 @@ static int jacobi_pcg(Ctx* c, const System& S, const Work& w, const double* b, d
     }
     it += burst;
     double rr[3];
-    PQ_HIP(hipMemcpyAsync(rr, &w.sc->rr[1][0], 24, hipMemcpyDeviceToHost, c->stream));
-    PQ_HIP(hipStreamSynchronize(c->stream));
+    {
+      const double* parts[1] = {w.sc->rr[1]};
+      PQ_TRY(part_totals_host(c, parts, 1, &rr));
+    }
     done = true;
     double worst = 0.0;
     for (int k = 0; k < 3; ++k) {
@@ -509,14 +512,36 @@ static int jacobi_pcg(Ctx* c, const System& S, const Work& w, const double* b, d
   return 0;
 }
 
+// d_tmp: a partial array [3][kPart]
 static int dot3_host(Ctx* c, int n, const double* a, const double* b, double* d_tmp,
                      double out[3]) {
-  PQ_HIP(hipMemsetAsync(d_tmp, 0, 24, c->stream));
-  hipLaunchKernelGGL(k_dot3, dim3(unsigned(std::min<int64_t>(ceil_div(n, 256), 1024))), dim3(256), 0, c->stream,
-                     n, a, b, d_tmp);
+  hipLaunchKernelGGL(k_dot3, dim3(reduce_grid(n)), dim3(256), 0, c->stream, n, a, b, d_tmp);
   PQ_HIP(hipGetLastError());
-  PQ_HIP(hipMemcpyAsync(out, d_tmp, 24, hipMemcpyDeviceToHost, c->stream));
+  const double* parts[1] = {d_tmp};
+  double t[1][3];
+  PQ_TRY(part_totals_host(c, parts, 1, t));
+  for (int k = 0; k < 3; ++k) out[k] = t[0][k];
+  return 0;
+}
+
+int part_totals_host(Ctx* c, const double* const* parts, int m, double (*out)[3]) {
+  std::vector<double> h(size_t(m) * 3 * kPart);
+  for (int a = 0; a < m; ++a)
+    PQ_HIP(hipMemcpyAsync(h.data() + size_t(a) * 3 * kPart, parts[a], sizeof(double) * 3 * kPart,
+                          hipMemcpyDeviceToHost, c->stream));
   PQ_HIP(hipStreamSynchronize(c->stream));
+  for (int a = 0; a < m; ++a)
+    for (int k = 0; k < 3; ++k) {
+      const double* p = h.data() + (size_t(a) * 3 + size_t(k)) * kPart;
+      double s[4] = {0, 0, 0, 0};  // four interleaved chains, then pairwise: fixed order
+      for (int i = 0; i < kPart; i += 4) {
+        s[0] += p[i];
+        s[1] += p[i + 1];
+        s[2] += p[i + 2];
+        s[3] += p[i + 3];
+      }
+      out[a][k] = (s[0] + s[1]) + (s[2] + s[3]);
+    }
   return 0;
 }
 
@@ -526,20 +551,22 @@ __global__ __launch_bounds__(256) void k_update_r(int n, const double* __restric
                                                   const double* __restrict__ q,
                                                   double* __restrict__ x, double* __restrict__ r,
                                                   Scal* __restrict__ sc, int par) {
-  int i = blockIdx.x * 256 + threadIdx.x;
-  double rr[3] = {0, 0, 0};
-  if (i < n) {
+  double rr[3] = {0, 0, 0}, pqt[3], rzt[3], alpha[3];
+  part_total3(sc->pq[par], pqt);
+  part_total3(sc->rz[par], rzt);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) alpha[k] = pqt[k] != 0.0 ? rzt[k] / pqt[k] : 0.0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {  // reduce_grid
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      const double pqk = sc->pq[par][k];
-      const double alpha = pqk != 0.0 ? sc->rz[par][k] / pqk : 0.0;
-      x[3 * i + k] += alpha * dir[3 * i + k];
-      const double ri = r[3 * i + k] - alpha * q[3 * i + k];
+      x[3 * i + k] += alpha[k] * dir[3 * i + k];
+      const double ri = r[3 * i + k] - alpha[k] * q[3 * i + k];
       r[3 * i + k] = ri;
-      rr[k] = ri * ri;
+      rr[k] += ri * ri;
     }
   }
-  reduce3_atomic(rr[0], rr[1], rr[2], sc->rr[par]);
+  __syncthreads();
+  reduce3_part(rr[0], rr[1], rr[2], sc->rr[par]);
 }
 
 // PYQSM_AMG_FIXED=m: every B-solve runs exactly m multigrid-CG iterations (experiment knob)
@@ -567,17 +594,17 @@ static int amg_pcg(Ctx* c, const System& S, const Work& w, AmgHierarchy* H, cons
   PQ_HIP(hipMemsetAsync(w.sc, 0, sizeof(Scal), c->stream));
   PQ_HIP(hipMemsetAsync(y, 0, size_t(N) * 24, c->stream));
   PQ_HIP(hipMemcpyAsync(w.r, rhs, size_t(N) * 24, hipMemcpyDeviceToDevice, c->stream));
-  hipLaunchKernelGGL(k_dot3, dim3(unsigned(std::min<int64_t>(ceil_div(N, 256), 1024))), block, 0, c->stream, N,
-                     rhs, rhs, w.sc->bb);
+  const dim3 rgrid(reduce_grid(N));
+  hipLaunchKernelGGL(k_dot3, rgrid, block, 0, c->stream, N, rhs, rhs, w.sc->bb);
   PQ_TRY(amg_vcycle(c, H, w.r, w.z, w.sc->rz[0]));
   PQ_HIP(hipMemcpyAsync(w.dir, w.z, size_t(N) * 24, hipMemcpyDeviceToDevice, c->stream));
   for (int k = 0; k < 3; ++k) resid[k] = 1.0;
   *iters = 0;
   auto iteration = [&](int par) -> int {
-    hipLaunchKernelGGL(k_spmv3_tail<OP_B>, grid, block, 0, c->stream, N, S.L.indptr, S.L.indices,
+    hipLaunchKernelGGL(k_spmv3_tail<OP_B>, rgrid, block, 0, c->stream, N, S.L.indptr, S.L.indices,
                        S.L.vals, w.dir, S.wl, S.wh, w.dir, w.q,
                        w.sc, par);
-    hipLaunchKernelGGL(k_update_r, grid, block, 0, c->stream, N, w.dir, w.q, y, w.r, w.sc, par);
+    hipLaunchKernelGGL(k_update_r, rgrid, block, 0, c->stream, N, w.dir, w.q, y, w.r, w.sc, par);
     PQ_TRY(amg_vcycle(c, H, w.r, w.z, w.sc->rz[par ^ 1]));
     hipLaunchKernelGGL(k_direction, grid, block, 0, c->stream, N, w.z, w.dir, w.sc, par);
     return 0;
@@ -617,11 +644,13 @@ static int amg_pcg(Ctx* c, const System& S, const Work& w, AmgHierarchy* H, cons
       PQ_TRY(run_burst(len));
     }
     it += len;
-    double h[6];  // rr[1][0..2], bb[0..2] are adjacent in Scal
-    PQ_HIP(hipMemcpyAsync(h, &w.sc->rr[1][0], 48, hipMemcpyDeviceToHost, c->stream));
-    PQ_HIP(hipStreamSynchronize(c->stream));
-    const double* rr = h;
-    const double* bb = h + 3;
+    double h[2][3];
+    {
+      const double* parts[2] = {w.sc->rr[1], w.sc->bb};
+      PQ_TRY(part_totals_host(c, parts, 2, h));
+    }
+    const double* rr = h[0];
+    const double* bb = h[1];
     if (bb[0] == 0.0 && bb[1] == 0.0 && bb[2] == 0.0) {  // zero right-hand side: y = 0
       for (int k = 0; k < 3; ++k) resid[k] = 0.0;
       *iters = it;
@@ -648,7 +677,15 @@ static int amg_pcg(Ctx* c, const System& S, const Work& w, AmgHierarchy* H, cons
 // fp32 altogether: B as the multigrid's fp32 level-0 matrix, float vectors, the cycle without
 // its conversion pass; dot products are still accumulated in fp64. Half the bytes per sparse
 // pass and vector update.
-static constexpr int kReduceBlocks = 1024;  // grid cap of kernels whose blocks end in same-address atomics
+// PYQSM_REDUCE_BLOCKS: grid cap of the reducing kernels of this loop below kPart (tuning knob)
+static unsigned reduce_grid_f(int64_t n) {
+  static const int cap = [] {
+    const char* e = getenv("PYQSM_REDUCE_BLOCKS");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? std::min(v, kPart) : kPart;
+  }();
+  return std::min<unsigned>(reduce_grid(n), unsigned(cap));
+}
 
 struct WorkF {
   float *r, *z, *dir, *q;
@@ -671,10 +708,7 @@ __global__ __launch_bounds__(256) void k_bspmv_f(int n, const int32_t* __restric
                                                  Scal* __restrict__ sc, int par) {
   const int gid = blockIdx.x * 256 + threadIdx.x;
   double pq[3] = {0, 0, 0};
-  if (gid < 3) sc->rz[par ^ 1][gid] = 0.0;  // the cycle of this iteration accumulates there
-  // grid-stride over the rows: the three atomics at the end are per BLOCK, and atomics on one
-  // address are served one at a time (4000 blocks cost ~40 us of a 70 us kernel)
-  for (int i = gid; i < n; i += gridDim.x * 256) {
+  for (int i = gid; i < n; i += gridDim.x * 256) {  // reduce_grid
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
     const int e = indptr[i + 1];
     for (int j = indptr[i]; j < e; j += kU) {  // kU entries' loads side by side (amg.hip: kRowUnroll)
@@ -702,20 +736,19 @@ __global__ __launch_bounds__(256) void k_bspmv_f(int n, const int32_t* __restric
     pq[1] += double(pi.y) * a1;
     pq[2] += double(pi.z) * a2;
   }
-  reduce3_atomic(pq[0], pq[1], pq[2], sc->pq[par]);
+  reduce3_part(pq[0], pq[1], pq[2], sc->pq[par]);
 }
 
 __global__ __launch_bounds__(256) void k_update_r_f(int n, const float* __restrict__ dir,
                                                     const float* __restrict__ q,
                                                     float* __restrict__ x, float* __restrict__ r,
                                                     Scal* __restrict__ sc, int par) {
-  double rr[3] = {0, 0, 0};
+  double rr[3] = {0, 0, 0}, pqt[3], rzt[3];
   float alpha[3];
+  part_total3(sc->pq[par], pqt);
+  part_total3(sc->rz[par], rzt);
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const double pqk = sc->pq[par][k];
-    alpha[k] = float(pqk != 0.0 ? sc->rz[par][k] / pqk : 0.0);
-  }
+  for (int k = 0; k < 3; ++k) alpha[k] = float(pqt[k] != 0.0 ? rzt[k] / pqt[k] : 0.0);
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     const float4 d = ld4(dir, i), qi = ld4(q, i), xi = ld4(x, i), ri = ld4(r, i);
     st4(x, i, xi.x + alpha[0] * d.x, xi.y + alpha[1] * d.y, xi.z + alpha[2] * d.z);
@@ -725,30 +758,27 @@ __global__ __launch_bounds__(256) void k_update_r_f(int n, const float* __restri
     rr[1] += double(r1) * r1;
     rr[2] += double(r2) * r2;
   }
-  reduce3_atomic(rr[0], rr[1], rr[2], sc->rr[par]);
+  __syncthreads();
+  reduce3_part(rr[0], rr[1], rr[2], sc->rr[par]);
 }
 
 __global__ __launch_bounds__(256) void k_direction_f(int n, const float* __restrict__ z,
                                                      float* __restrict__ dir, Scal* __restrict__ sc,
                                                      int par) {
   int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < 3) {  // slots the next iteration accumulates into
-    sc->pq[par ^ 1][i] = 0.0;
-    sc->rr[par ^ 1][i] = 0.0;
-  }
+  double rzo[3], rzn[3];
+  part_total3(sc->rz[par], rzo);
+  part_total3(sc->rz[par ^ 1], rzn);
   if (i >= n) return;
   float beta[3];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const double rzk = sc->rz[par][k];
-    beta[k] = float(rzk != 0.0 ? sc->rz[par ^ 1][k] / rzk : 0.0);
-  }
+  for (int k = 0; k < 3; ++k) beta[k] = float(rzo[k] != 0.0 ? rzn[k] / rzo[k] : 0.0);
   const float4 zi = ld4(z, i), d = ld4(dir, i);
   st4(dir, i, zi.x + beta[0] * d.x, zi.y + beta[1] * d.y, zi.z + beta[2] * d.z);
 }
 
 __global__ __launch_bounds__(256) void k_dot3_f(int n, const float* __restrict__ a,
-                                                double* __restrict__ out) {
+                                                double* __restrict__ out /*[3][kPart]*/) {
   double d[3] = {0, 0, 0};
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     const float4 t = ld4(a, i);
@@ -756,7 +786,7 @@ __global__ __launch_bounds__(256) void k_dot3_f(int n, const float* __restrict__
     d[1] += double(t.y) * t.y;
     d[2] += double(t.z) * t.z;
   }
-  reduce3_atomic(d[0], d[1], d[2], out);
+  reduce3_part(d[0], d[1], d[2], out);
 }
 
 // fp64 [n,3] <-> fp32 rows of kVecStride floats
@@ -787,7 +817,7 @@ static int amg_pcg_f32(Ctx* c, int N, const WorkF& w, AmgHierarchy* H, const flo
   PQ_HIP(hipMemsetAsync(w.sc, 0, sizeof(Scal), c->stream));
   PQ_HIP(hipMemsetAsync(y, 0, size_t(N) * kVecStride * 4, c->stream));
   PQ_HIP(hipMemcpyAsync(w.r, rhs, size_t(N) * kVecStride * 4, hipMemcpyDeviceToDevice, c->stream));
-  const dim3 rgrid(unsigned(std::min<int64_t>(ceil_div(N, 256), kReduceBlocks)));  // kernels that end in atomics
+  const dim3 rgrid(reduce_grid_f(N));  // kernels that end in a reduction
   hipLaunchKernelGGL(k_dot3_f, rgrid, block, 0, c->stream, N, rhs, w.sc->bb);
   PQ_TRY(amg_vcycle_f32(c, H, w.r, w.z, w.sc->rz[0]));
   PQ_HIP(hipMemcpyAsync(w.dir, w.z, size_t(N) * kVecStride * 4, hipMemcpyDeviceToDevice, c->stream));
@@ -850,11 +880,13 @@ static int amg_pcg_f32(Ctx* c, int N, const WorkF& w, AmgHierarchy* H, const flo
       PQ_TRY(run_burst(len));
     }
     it += len;
-    double h[6];  // rr[1][0..2], bb[0..2] are adjacent in Scal
-    PQ_HIP(hipMemcpyAsync(h, &w.sc->rr[1][0], 48, hipMemcpyDeviceToHost, c->stream));
-    PQ_HIP(hipStreamSynchronize(c->stream));
-    const double* rr = h;
-    const double* bb = h + 3;
+    double h[2][3];
+    {
+      const double* parts[2] = {w.sc->rr[1], w.sc->bb};
+      PQ_TRY(part_totals_host(c, parts, 2, h));
+    }
+    const double* rr = h[0];
+    const double* bb = h[1];
     if (bb[0] == 0.0 && bb[1] == 0.0 && bb[2] == 0.0) {
       for (int k = 0; k < 3; ++k) resid[k] = 0.0;
       *iters = it;
@@ -894,7 +926,7 @@ static int lbc_solve_core(Ctx* c, const DevCsr& L, int64_t n, const double* wl, 
   double *b, *minv_a, *d_tmp;
   PQ_TRY(c->arena.get(size_t(n) * 3, &b));
   PQ_TRY(c->arena.get(size_t(n), &minv_a));
-  PQ_TRY(c->arena.get(3, &d_tmp));
+  PQ_TRY(c->arena.get(size_t(3) * kPart, &d_tmp));
   hipLaunchKernelGGL(k_rhs, grid, block, 0, c->stream, N, wh, pts, b);
   PQ_HIP(hipMemcpyAsync(x, pts, size_t(n) * 24, hipMemcpyDeviceToDevice, c->stream));
   Work wa;
@@ -1112,6 +1144,17 @@ __global__ __launch_bounds__(256) void k_edge_const(int n, const int32_t* __rest
 // array; sorted by grid cell they sit within a few cache lines of each other. The solve
 // therefore runs on P L P', P w, P p and un-permutes the result (measured on the 1 M-point
 // forest: -22 % per multigrid-CG iteration; the permutation costs ~1 ms per solve).
+// key of every point = its grid cell, value = its index: the input of the stable sort
+__global__ __launch_bounds__(256) void k_perm_keys(int n, const int32_t* __restrict__ gorder,
+                                                   const int32_t* __restrict__ cell_of,
+                                                   uint32_t* __restrict__ keys,
+                                                   int32_t* __restrict__ vals) {
+  int f = blockIdx.x * 256 + threadIdx.x;
+  if (f >= n) return;
+  keys[gorder[f]] = uint32_t(cell_of[f]);
+  vals[f] = f;
+}
+
 __global__ __launch_bounds__(256) void k_perm_invert(int n, const int32_t* __restrict__ order,
                                                      int32_t* __restrict__ pos_of) {
   int i = blockIdx.x * 256 + threadIdx.x;
@@ -1186,6 +1229,18 @@ int lbc_solve_device(Ctx* c, const DevCsr& L, int64_t n, const double* wl, bool 
   double box[6] = {mn[0], mn[1], mn[2], mx[0], mx[1], mx[2]};
   DevGrid g;
   PQ_TRY(build_grid(c, pts, n, ext / 512.0, int64_t(1) << 24, &g, box));
+  // The grid's own order inside a cell is the arrival order of atomics. The unknowns are
+  // numbered by (cell, original index) instead — a stable sort — so that the same system is
+  // the same numbering, the same aggregates and the same rounding on every run.
+  uint32_t* keys = nullptr;
+  int32_t* order = nullptr;
+  PQ_TRY(c->arena.get(size_t(n), &keys));
+  PQ_TRY(c->arena.get(size_t(n), &order));
+  hipLaunchKernelGGL(k_perm_keys, grid, block, 0, c->stream, N, g.order, g.cell_of, keys, order);
+  PQ_HIP(hipGetLastError());
+  int bits = 1;
+  while (bits < 32 && (int64_t(1) << bits) < g.ncell) ++bits;
+  PQ_TRY(stable_sort_pairs_u32(c, &keys, &order, n, bits));
   int32_t nnz = 0;
   PQ_HIP(hipMemcpyAsync(&nnz, L.indptr + n, 4, hipMemcpyDeviceToHost, c->stream));
   PQ_HIP(hipStreamSynchronize(c->stream));
@@ -1200,15 +1255,15 @@ int lbc_solve_device(Ctx* c, const DevCsr& L, int64_t n, const double* wl, bool 
   PQ_TRY(c->arena.get(size_t(n), &wl_p));
   PQ_TRY(c->arena.get(size_t(n) * 3, &pts_p));
   PQ_TRY(c->arena.get(size_t(n) * 3, &x_p));
-  hipLaunchKernelGGL(k_perm_invert, grid, block, 0, c->stream, N, g.order, pos_of);
-  hipLaunchKernelGGL(k_perm_rowlen, grid1, block, 0, c->stream, N, g.order, L.indptr, Lp.indptr);
+  hipLaunchKernelGGL(k_perm_invert, grid, block, 0, c->stream, N, order, pos_of);
+  hipLaunchKernelGGL(k_perm_rowlen, grid1, block, 0, c->stream, N, order, L.indptr, Lp.indptr);
   PQ_TRY(exclusive_scan_i32(c, Lp.indptr, n + 1));
-  hipLaunchKernelGGL(k_perm_fill, grid, block, 0, c->stream, N, g.order, pos_of, L.indptr, L.indices,
+  hipLaunchKernelGGL(k_perm_fill, grid, block, 0, c->stream, N, order, pos_of, L.indptr, L.indices,
                      L.vals, Lp.indptr, Lp.indices, Lp.vals, wh, wl, pts, wh_p, wl_p, pts_p);
   PQ_HIP(hipGetLastError());
   const int rc = lbc_solve_core(c, Lp, n, wl_p, wl_edge_const, wh_p, pts_p, rtol, max_it, x_p, iters, resid);
   if (rc != 0 && rc != PYQSM_ENOCONV) return rc;
-  hipLaunchKernelGGL(k_perm_back, grid, block, 0, c->stream, N, g.order, x_p, x);
+  hipLaunchKernelGGL(k_perm_back, grid, block, 0, c->stream, N, order, x_p, x);
   PQ_HIP(hipGetLastError());
   return rc;
 }

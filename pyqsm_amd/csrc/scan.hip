@@ -1,6 +1,8 @@
 // scan.hip — device-wide exclusive prefix sum of int32 (three-phase: per-block
 // reduce, recursive scan of the block sums, per-block scan + offset). HBM-bound:
 // 2 reads + 1 write of the array, all as whole cache lines per wave.
+#include <utility>
+
 #include "common.hpp"
 
 namespace pyqsm {
@@ -142,6 +144,101 @@ int exclusive_scan_i32(Ctx* c, int32_t* data, int64_t n) {
   PQ_TRY(exclusive_scan_i32(c, sums, nb));
   launch_apply(c, nb, data, n, sums);
   PQ_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---- stable radix sort of (key, value) pairs ----------------------------------------------------
+// Least-significant-digit passes of 8 bits; each pass is a per-tile digit histogram, the scan
+// above over [digit][tile], and a scatter in which a pair's place among the equal digits of its
+// tile follows its position in the tile (ballot ranks inside a wave, waves and rounds in order).
+// No global atomics: the result is THE stable order, the same bits on every run — which is what
+// the contraction solve needs from its spatial ordering (lbc.hip), where an order that depends
+// on the scheduling of atomics ends up in the rounding of every dot product.
+
+static constexpr int kSortRounds = 8;                        // rounds of 256 pairs per block
+static constexpr int kSortTile = kScanThreads * kSortRounds;  // 2048
+
+__global__ __launch_bounds__(256) void k_radix_hist(const uint32_t* __restrict__ keys, int64_t n,
+                                                    int shift, int32_t* __restrict__ bh, int nb) {
+  __shared__ int h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t base = int64_t(blockIdx.x) * kSortTile;
+#pragma unroll
+  for (int r = 0; r < kSortRounds; ++r) {
+    const int64_t i = base + r * 256 + threadIdx.x;
+    if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255u], 1);  // LDS; counts do not depend on the order
+  }
+  __syncthreads();
+  bh[size_t(threadIdx.x) * nb + blockIdx.x] = h[threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void k_radix_scatter(const uint32_t* __restrict__ keys,
+                                                       const int32_t* __restrict__ vals, int64_t n,
+                                                       int shift, const int32_t* __restrict__ bh, int nb,
+                                                       uint32_t* __restrict__ keys_out,
+                                                       int32_t* __restrict__ vals_out) {
+  __shared__ int base[256];     // next free place of each digit for this tile
+  __shared__ int wcnt[4][256];  // digit counts of the four waves in the current round
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  base[threadIdx.x] = bh[size_t(threadIdx.x) * nb + blockIdx.x];
+  const int64_t tile = int64_t(blockIdx.x) * kSortTile;
+  for (int r = 0; r < kSortRounds; ++r) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) wcnt[q][threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t i = tile + r * 256 + threadIdx.x;
+    const bool live = i < n;
+    const uint32_t key = live ? keys[i] : 0u;
+    const int val = live ? vals[i] : 0;
+    const int digit = int((key >> shift) & 255u);
+    unsigned long long peers = __ballot(live);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const bool bit = (digit >> b) & 1;
+      const unsigned long long bal = __ballot(bit);
+      peers &= bit ? bal : ~bal;
+    }
+    const int rank = __popcll(peers & ((1ull << lane) - 1ull));
+    if (live && rank == 0) wcnt[w][digit] = __popcll(peers);
+    __syncthreads();
+    if (live) {
+      int off = 0;
+      for (int q = 0; q < w; ++q) off += wcnt[q][digit];
+      const int pos = base[digit] + off + rank;
+      keys_out[pos] = key;
+      vals_out[pos] = val;
+    }
+    __syncthreads();
+    base[threadIdx.x] += (wcnt[0][threadIdx.x] + wcnt[1][threadIdx.x]) +
+                         (wcnt[2][threadIdx.x] + wcnt[3][threadIdx.x]);
+    __syncthreads();
+  }
+}
+
+int stable_sort_pairs_u32(Ctx* c, uint32_t** keys, int32_t** vals, int64_t n, int bits) {
+  if (n <= 1 || bits <= 0) return 0;
+  if (n > 0x7FFFFF00LL) return fail(PYQSM_ERANGE, "more than 2^31 pairs to sort");
+  const int nb = int((n + kSortTile - 1) / kSortTile);
+  uint32_t* k2 = nullptr;
+  int32_t *v2 = nullptr, *bh = nullptr;
+  PQ_TRY(c->arena.get(size_t(n), &k2));
+  PQ_TRY(c->arena.get(size_t(n), &v2));
+  PQ_TRY(c->arena.get(size_t(256) * nb + 1, &bh));
+  uint32_t *ka = *keys, *kb = k2;
+  int32_t *va = *vals, *vb = v2;
+  for (int shift = 0; shift < bits; shift += 8) {
+    hipLaunchKernelGGL(k_radix_hist, dim3(unsigned(nb)), dim3(256), 0, c->stream, ka, n, shift, bh, nb);
+    PQ_HIP(hipGetLastError());
+    PQ_TRY(exclusive_scan_i32(c, bh, int64_t(256) * nb));
+    hipLaunchKernelGGL(k_radix_scatter, dim3(unsigned(nb)), dim3(256), 0, c->stream, ka, va, n, shift, bh,
+                       nb, kb, vb);
+    PQ_HIP(hipGetLastError());
+    std::swap(ka, kb);
+    std::swap(va, vb);
+  }
+  *keys = ka;
+  *vals = va;
   return 0;
 }
 

@@ -44,23 +44,6 @@ __global__ __launch_bounds__(256) void k_fill_const(int n, double v, double* __r
   if (i < n) out[i] = v;
 }
 
-// sum of v over every segment: one block per segment, fixed tree (deterministic)
-__global__ __launch_bounds__(256) void k_seg_sum(const int32_t* __restrict__ seg_start,
-                                                 const double* __restrict__ v,
-                                                 double* __restrict__ out) {
-  __shared__ double red[256];
-  const int s = blockIdx.x;
-  double acc = 0.0;
-  for (int i = seg_start[s] + threadIdx.x; i < seg_start[s + 1]; i += 256) acc += v[i];
-  red[threadIdx.x] = acc;
-  __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
-    if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) out[s] = red[0];
-}
-
 // flags[s]: bit 0 = some coordinate of the new positions differs from the current ones
 // ((new == cur).all() of :287 is false), bit 1 = some coordinate of the new positions is not NaN
 // (least_squares_sparse returns the input when EVERYTHING is NaN, :177-179)
@@ -151,7 +134,48 @@ struct DevBlock {  // hipMalloc'ed memory of one call, released on every exit pa
 
 using namespace pyqsm;
 
+// NumPy's pairwise summation (numpy/_core/src/umath/loops_utils.h.src, @TYPE@_pairwise_sum, as
+// published: below 8 values a plain loop; up to 128 values eight running sums over the multiples
+// of 8, combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then the rest one by one; above that the
+// array is split at n/2 rounded down to a multiple of 8). Restated here, not linked: the point is
+// the ORDER of the additions.
+static double np_pairwise_sum(const double* a, int64_t n) {
+  if (n < 8) {
+    double res = 0.0;
+    for (int64_t i = 0; i < n; ++i) res += a[i];
+    return res;
+  }
+  if (n <= 128) {
+    double r[8];
+    for (int j = 0; j < 8; ++j) r[j] = a[j];
+    int64_t i = 8;
+    for (; i < n - (n % 8); i += 8)
+      for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += a[i];
+    return res;
+  }
+  int64_t n2 = n / 2;
+  n2 -= n2 % 8;
+  return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
+}
+
 extern "C" {
+
+int pyqsm_mean_f64(const double* v, int64_t n, double* out) {
+  if (!out) return fail(PYQSM_EINVAL, "null output");
+  if (n <= 0 || !v) {
+    *out = std::nan("");
+    return 0;
+  }
+  // np.add.reduce hands its inner loop at most one buffer (8192 elements, np.getbufsize()'s
+  // default) at a time and adds the pieces' pairwise sums up in order (NumPy 2.2 checked: the
+  // whole-array pairwise sum differs from np.sum in the last bit for some n > 8192, this does not)
+  double acc = 0.0;
+  for (int64_t b = 0; b < n; b += 8192) acc += np_pairwise_sum(v + b, std::min<int64_t>(8192, n - b));
+  *out = acc / double(n);
+  return 0;
+}
 
 int pyqsm_extract_skeleton(const double* xyz, int64_t n, const int64_t* seg_start, int64_t n_seg,
                            int32_t k, double moll, int32_t max_iter, double termination_ratio,
@@ -238,16 +262,18 @@ int pyqsm_extract_skeleton(const double* xyz, int64_t n, const int64_t* seg_star
     c->arena.rewind(base);
     return 0;
   };
-  std::vector<double> h_sum(static_cast<size_t>(S)), mean0(static_cast<size_t>(S)), mean_used(static_cast<size_t>(S)),
+  std::vector<double> mean0(static_cast<size_t>(S)), mean_used(static_cast<size_t>(S)),
       wl_seg(static_cast<size_t>(S)), vr(static_cast<size_t>(S), 1.0);
   std::vector<int32_t> active(static_cast<size_t>(S), 1), iteration(static_cast<size_t>(S), 0),
       h_flags(static_cast<size_t>(S));
+  // per-cloud means with NumPy's summation order (pyqsm_mean_f64: what np.mean of the Python loop
+  // returns, bit for bit); 8 bytes per point come to the host for it, once per step
+  std::vector<double> h_vec(static_cast<size_t>(n));
   auto seg_means = [&](const double* v, std::vector<double>& out) -> int {
-    hipLaunchKernelGGL(k_seg_sum, dim3(unsigned(S)), blk, 0, c->stream, d_seg_start, v, d_segval);
-    PQ_HIP(hipGetLastError());
-    PQ_HIP(hipMemcpyAsync(h_sum.data(), d_segval, size_t(S) * 8, hipMemcpyDeviceToHost, c->stream));
+    PQ_HIP(hipMemcpyAsync(h_vec.data(), v, size_t(n) * 8, hipMemcpyDeviceToHost, c->stream));
     PQ_HIP(hipStreamSynchronize(c->stream));
-    for (int s = 0; s < S; ++s) out[size_t(s)] = h_sum[size_t(s)] / double(seg_start[s + 1] - seg_start[s]);
+    for (int s = 0; s < S; ++s)
+      pyqsm_mean_f64(h_vec.data() + seg_start[s], seg_start[s + 1] - seg_start[s], &out[size_t(s)]);
     return 0;
   };
   PQ_TRY(build());                                                                    // :253-255

@@ -1,6 +1,8 @@
 // sparse.hpp — CSR handle shared by the contraction solve and its multilevel
 // preconditioner.
 #pragma once
+#include <algorithm>
+
 #include "common.hpp"
 
 namespace pyqsm {
@@ -10,8 +12,25 @@ struct DevCsr {
   double* vals;
 };
 
-// Block reduction of three partial sums followed by one fp64 atomic per column.
-__device__ __forceinline__ void reduce3_atomic(double v0, double v1, double v2, double* out) {
+// ---- reproducible reductions ----------------------------------------------------------------
+// The dot products of the solver are NOT accumulated with atomics: an fp64 atomicAdd per block
+// makes the order of the additions, and with it the last bits of every CG scalar, a matter of
+// scheduling, and the contraction loop amplifies those bits into 1e-4 relative differences of the
+// skeleton between two runs on the same input. Instead every block of a reducing kernel stores
+// its three sums into its own slot of a partial array [3][kPart], and every block of a consuming
+// kernel adds the kPart partials up again in one fixed order (12 loads per thread and a block
+// reduction; the partials sit in L2). Same input, same bits, whatever the scheduling. It is also
+// faster: kPart same-address atomics per launch were served one at a time (~9 ns each, measured:
+// 1024 blocks 33.6 us, 4096 blocks 57.6 us for the same pass).
+static constexpr int kPart = 1024;  // slots per column; a reducing kernel's grid is at most this
+
+// Grid of a kernel that ends in reduce3_part (its row loop strides by the grid).
+inline unsigned reduce_grid(int64_t n) { return unsigned(std::min<int64_t>(std::max<int64_t>(ceil_div(n, 256), 1), kPart)); }
+
+// Block reduction of three per-thread sums into this block's slot of part[3][kPart]; block 0
+// clears the slots past the grid. 256 threads per block, gridDim.x <= kPart. Two calls in one
+// kernel need a __syncthreads() between them.
+__device__ __forceinline__ void reduce3_part(double v0, double v1, double v2, double* __restrict__ part) {
   __shared__ double red[3][4];
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
@@ -26,12 +45,45 @@ __device__ __forceinline__ void reduce3_atomic(double v0, double v1, double v2, 
     red[2][w] = v2;
   }
   __syncthreads();
-  if (threadIdx.x < 3) {
-    double t = (red[threadIdx.x][0] + red[threadIdx.x][1]) +
-               (red[threadIdx.x][2] + red[threadIdx.x][3]);
-    atomicAdd(out + threadIdx.x, t);
-  }
+  if (threadIdx.x < 3)
+    part[threadIdx.x * kPart + blockIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) +
+                                             (red[threadIdx.x][2] + red[threadIdx.x][3]);
+  if (blockIdx.x == 0)
+    for (int s = int(gridDim.x) + int(threadIdx.x); s < kPart; s += 256)
+      part[s] = part[kPart + s] = part[2 * kPart + s] = 0.0;
 }
+
+// The three totals of a partial array: the same bits in every thread of every block. Every
+// thread of the (256-thread) block must call it.
+__device__ __forceinline__ void part_total3(const double* __restrict__ part, double out[3]) {
+  __shared__ double tot[3][4];
+  const int t = threadIdx.x;
+  double s[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double* p = part + k * kPart;
+    s[k] = (p[t] + p[t + 256]) + (p[t + 512] + p[t + 768]);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    s[0] += __shfl_down(s[0], off, 64);
+    s[1] += __shfl_down(s[1], off, 64);
+    s[2] += __shfl_down(s[2], off, 64);
+  }
+  __syncthreads();  // an earlier call's readers are done with tot
+  if ((t & 63) == 0) {
+    tot[0][t >> 6] = s[0];
+    tot[1][t >> 6] = s[1];
+    tot[2][t >> 6] = s[2];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 3; ++k) out[k] = (tot[k][0] + tot[k][1]) + (tot[k][2] + tot[k][3]);
+}
+static_assert(kPart == 1024, "part_total3 adds four partials per thread of a 256-thread block");
+
+// The totals on the host, in a fixed order as well (24 KB per array; the stream is drained).
+int part_totals_host(Ctx* c, const double* const* parts, int m, double (*out)[3]);
 
 // Aggregation multigrid for B = c*L + diag(wh) (amg.hip). Opaque to callers.
 struct AmgHierarchy;
@@ -45,7 +97,8 @@ int amg_levels(const AmgHierarchy* h);
 
 // x = M^-1 b for three columns: one symmetric V(1,1) cycle (l1-Jacobi smoothing,
 // piecewise-constant strength-based aggregation, dense solve on the coarsest level).
-// When `dot` is given, dot[0..2] += b . x per column (fused into the last kernel).
+// When `dot` is given it is a partial array [3][kPart] that receives b . x per column (fused
+// into the last kernel, see reduce3_part).
 int amg_vcycle(Ctx* c, AmgHierarchy* h, const double* b, double* x, double* dot = nullptr);
 // Floats per row of an fp32 solver vector: (x, y, z, 0), so that a row is one 16-byte access.
 static constexpr int kVecStride = 4;

@@ -338,8 +338,8 @@ def _contract_group(clouds, moll, n_neighbors, max_iter, termination_ratio, cont
     hi = np.concatenate([np.tile(b[1] + o, (n, 1)) for b, o, n in zip(bounds, offs, sizes)])
     cur = np.concatenate([p + o for p, o in zip(pts, offs)])
 
-    def seg_mean(v):
-        return np.add.reduceat(v, start[:-1]) / sizes
+    def seg_mean(v):   # np.mean per cloud: the summation order of the single-cloud loop (:265)
+        return np.array([v[a:b].mean() for a, b in zip(start[:-1], start[1:])])
 
     L, M = point_cloud_laplacian(cur, mollify_factor=moll, n_neighbors=n_neighbors, device=device,
                                  seg_start=start)

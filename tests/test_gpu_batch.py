@@ -22,16 +22,18 @@ def _trees(k, n):
 def test_batch_equals_per_cloud_loop(gpu, c):
     """First contraction: the two paths solve the same systems (same Laplacian blocks, same
     weights) and agree to the solver's tolerance. Later steps: the loop amplifies rounding
-    differences through the Laplacian rebuilds on nearly degenerate contracted geometry — the
-    per-cloud loop run TWICE differs from itself by up to ~1e-4 on these small clouds (the dot
-    products of the solve are summed by atomics in arrival order), and by the same amount on a
-    rigidly translated copy — so the batch is held to a small multiple of that spread, which is
-    measured here, not to a fixed bound."""
+    differences through the Laplacian rebuilds on nearly degenerate contracted geometry. A run
+    is reproducible bit for bit (test_gpu_reproducible.py), but the batch shares its CG scalars
+    between the clouds of a group, so it differs from the per-cloud loop in the last bits of every
+    solve. What those last bits grow to is measured here: the per-cloud loop on a copy of the
+    cloud moved by ONE ULP in x differs from the original by up to ~1e-4 on these small clouds,
+    and the batch is held to a small multiple of that, not to a fixed bound."""
     clouds = _trees(5, 6000)
     iters = 8
     kw = dict(max_iter=iters, termination_ratio=0.0, contraction_factor=c, attraction_factor=3)
     single = [sk.extract_skeleton(P, **kw) for P in clouds]
-    again = [sk.extract_skeleton(P, **kw) for P in clouds]
+    again = [sk.extract_skeleton(np.column_stack([np.nextafter(P[:, 0], np.inf), P[:, 1:]]), **kw)
+             for P in clouds]
     batch = sk.extract_skeleton_batch(clouds, group_points=20_000, workers=2, **kw)     # 2 groups
     assert len(batch) == len(clouds)
     spread = worst = first = 0.0
@@ -45,9 +47,9 @@ def test_batch_equals_per_cloud_loop(gpu, c):
         assert np.abs(t2 - (P - g2.points)).max() < 1e-9
         assert all(q["ok"] for q in g2.solve_log)
     print(f"c={c}: first step {first:.1e}; over {iters} steps batch vs loop {worst:.1e}, "
-          f"loop vs itself {spread:.1e}")
+          f"loop on a one-ulp copy {spread:.1e}")
     assert first <= 2e-7
-    assert worst <= max(30.0 * spread, 3e-4)      # 3e-4: the largest spread seen on clouds of this size
+    assert worst <= max(30.0 * spread, 3e-4)      # 3e-4: the largest one-ulp response seen at this size
 
 
 def test_batch_termination_is_per_cloud(gpu):

@@ -282,3 +282,22 @@ def test_library_and_python_shard_the_same_way():
             assert prev == n
     b, e = ctypes.c_int64(0), ctypes.c_int64(0)
     assert lib.pyqsm_shard_bounds(10, 2, 2, ctypes.byref(b), ctypes.byref(e)) == -1
+
+
+def test_mean_f64_is_numpy_mean_bit_for_bit():
+    """pyqsm_mean_f64 (host code of the native contraction loop): np.mean's summation order —
+    pairwise blocks inside 8192-element buffers — so that the initial Laplacian weight
+    10^3 c sqrt(mean M) (skeletonize.py:265) is the same double in both engines."""
+    import ctypes
+    from pyqsm_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(0)
+    sizes = list(range(1, 260)) + [1000, 4097, 8191, 8192, 8193, 16385, 65537, 100003, 300001, 1_000_000]
+    sizes += [int(q) for q in rng.integers(1, 300_000, 60)]
+    for n in sizes:
+        v = rng.random(n) * float(rng.choice([1e-6, 1.0, 1e3]))
+        out = ctypes.c_double()
+        assert lib.pyqsm_mean_f64(v.ctypes.data_as(ctypes.c_void_p), n, ctypes.byref(out)) == 0
+        assert out.value == float(np.mean(v)), n
+    out = ctypes.c_double(1.0)
+    assert lib.pyqsm_mean_f64(None, 0, ctypes.byref(out)) == 0 and np.isnan(out.value)
