@@ -78,7 +78,7 @@ struct AmgLevel {
 
 struct AmgHierarchy {
   std::vector<AmgLevel> lv;
-  double* dense_inv = nullptr;  // [nc, nc] on the device
+  double* dense_inv = nullptr;  // [nc, nc] on the device, transposed
   int nc = 0;
 };
 
@@ -454,14 +454,9 @@ static constexpr int kRowUnroll = 8;
 
 // pre-smoothing from a zero start fused with the residual:
 //   x = Dinv b ;  r = b - A x
-__global__ __launch_bounds__(256) void k_down(int n, const int32_t* __restrict__ indptr,
-                                              const int32_t* __restrict__ indices,
-                                              const float* __restrict__ valsd /* a_ij / l1_j */,
-                                              const float* __restrict__ dinv,
-                                              const float* __restrict__ b, float* __restrict__ x,
-                                              float* __restrict__ r) {
-  int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
+__device__ __forceinline__ void down_row(int i, const int32_t* indptr, const int32_t* indices,
+                                         const float* valsd /* a_ij / l1_j */, const float* dinv,
+                                         const float* b, float* x, float* r) {
   float a0 = 0.f, a1 = 0.f, a2 = 0.f;
   const int e = indptr[i + 1];
   for (int j = indptr[i]; j < e; j += kRowUnroll) {
@@ -489,13 +484,19 @@ __global__ __launch_bounds__(256) void k_down(int n, const int32_t* __restrict__
   st4(r, i, bi.x - a0, bi.y - a1, bi.z - a2);
 }
 
+__global__ __launch_bounds__(256) void k_down(int n, const int32_t* __restrict__ indptr,
+                                              const int32_t* __restrict__ indices,
+                                              const float* __restrict__ valsd,
+                                              const float* __restrict__ dinv,
+                                              const float* __restrict__ b, float* __restrict__ x,
+                                              float* __restrict__ r) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) down_row(i, indptr, indices, valsd, dinv, b, x, r);
+}
+
 // rc[a] = sum of r over the members of aggregate a
-__global__ __launch_bounds__(256) void k_restrict(int nc, const int32_t* __restrict__ mptr,
-                                                  const int32_t* __restrict__ members,
-                                                  const float* __restrict__ r,
-                                                  float* __restrict__ rc) {
-  int a = blockIdx.x * 256 + threadIdx.x;
-  if (a >= nc) return;
+__device__ __forceinline__ void restrict_row(int a, const int32_t* mptr, const int32_t* members,
+                                             const float* r, float* rc) {
   float s0 = 0.f, s1 = 0.f, s2 = 0.f;
   const int e = mptr[a + 1];
   for (int m = mptr[a]; m < e; m += kRowUnroll) {
@@ -513,6 +514,14 @@ __global__ __launch_bounds__(256) void k_restrict(int nc, const int32_t* __restr
     }
   }
   st4(rc, a, s0, s1, s2);
+}
+
+__global__ __launch_bounds__(256) void k_restrict(int nc, const int32_t* __restrict__ mptr,
+                                                  const int32_t* __restrict__ members,
+                                                  const float* __restrict__ r,
+                                                  float* __restrict__ rc) {
+  int a = blockIdx.x * 256 + threadIdx.x;
+  if (a < nc) restrict_row(a, mptr, members, r, rc);
 }
 
 // coarse correction fused with the post-smoothing sweep:
@@ -590,6 +599,47 @@ __global__ __launch_bounds__(256) void k_up(int n, const int32_t* __restrict__ i
 
 // The same upward step through A P (see AmgLevel::ap_ptr): with x = Dinv b and r = b - A x from
 // the downward sweep,  y = x + P xc,  b - A y = r - (A P) xc,  out = y + Dinv (r - (A P) xc).
+__device__ __forceinline__ void up_ap_row(int i, const int32_t* ap_ptr, const int32_t* ap_idx,
+                                          const float* ap_val, const float* dinv, const int32_t* agg,
+                                          const float* xc, const float* r, const float* x, float& o0,
+                                          float& o1, float& o2) {
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+  const int e = ap_ptr[i + 1];
+  for (int j = ap_ptr[i]; j < e; j += 4) {
+    int ac[4];
+    float v[4];
+    float4 c4[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {  // past the row's end: coarse row 0 with weight 0
+      const bool ok = j + u < e;
+      ac[u] = ok ? ap_idx[j + u] : 0;
+      v[u] = ok ? ap_val[j + u] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) c4[u] = ld4(xc, ac[u]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      a0 += v[u] * c4[u].x;
+      a1 += v[u] * c4[u].y;
+      a2 += v[u] * c4[u].z;
+    }
+  }
+  const int ai = agg[i];
+  const float4 xi = ld4(x, i);
+  float y0 = xi.x, y1 = xi.y, y2 = xi.z;
+  if (ai >= 0) {
+    const float4 c4 = ld4(xc, ai);
+    y0 += c4.x;
+    y1 += c4.y;
+    y2 += c4.z;
+  }
+  const float d = dinv[i];
+  const float4 ri = ld4(r, i);
+  o0 = y0 + d * (ri.x - a0);
+  o1 = y1 + d * (ri.y - a1);
+  o2 = y2 + d * (ri.z - a2);
+}
+
 template <typename TO, typename TBD>
 __global__ __launch_bounds__(256) void k_up_ap(int n, const int32_t* __restrict__ ap_ptr,
                                                const int32_t* __restrict__ ap_idx,
@@ -603,39 +653,8 @@ __global__ __launch_bounds__(256) void k_up_ap(int n, const int32_t* __restrict_
                                                double* __restrict__ dot /*[3][kPart], may be null*/) {
   double d0 = 0.0, d1 = 0.0, d2 = 0.0;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-    const int e = ap_ptr[i + 1];
-    for (int j = ap_ptr[i]; j < e; j += 4) {
-      int ac[4];
-      float v[4];
-      float4 c4[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {  // past the row's end: coarse row 0 with weight 0
-        const bool ok = j + u < e;
-        ac[u] = ok ? ap_idx[j + u] : 0;
-        v[u] = ok ? ap_val[j + u] : 0.f;
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) c4[u] = ld4(xc, ac[u]);
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        a0 += v[u] * c4[u].x;
-        a1 += v[u] * c4[u].y;
-        a2 += v[u] * c4[u].z;
-      }
-    }
-    const int ai = agg[i];
-    const float4 xi = ld4(x, i);
-    float y0 = xi.x, y1 = xi.y, y2 = xi.z;
-    if (ai >= 0) {
-      const float4 c4 = ld4(xc, ai);
-      y0 += c4.x;
-      y1 += c4.y;
-      y2 += c4.z;
-    }
-    const float d = dinv[i];
-    const float4 ri = ld4(r, i);
-    const float o0 = y0 + d * (ri.x - a0), o1 = y1 + d * (ri.y - a1), o2 = y2 + d * (ri.z - a2);
+    float o0, o1, o2;
+    up_ap_row(i, ap_ptr, ap_idx, ap_val, dinv, agg, xc, r, x, o0, o1, o2);
     st_row(out, i, o0, o1, o2);
     if (bd) {
       TBD e0, e1, e2;
@@ -649,14 +668,9 @@ __global__ __launch_bounds__(256) void k_up_ap(int n, const int32_t* __restrict_
 }
 
 // one l1-Jacobi sweep out = x + Dinv (b - A x)   (coarsest level without a dense inverse)
-__global__ __launch_bounds__(256) void k_sweep(int n, const int32_t* __restrict__ indptr,
-                                               const int32_t* __restrict__ indices,
-                                               const float* __restrict__ vals,
-                                               const float* __restrict__ dinv,
-                                               const float* __restrict__ b,
-                                               const float* __restrict__ x, float* __restrict__ out) {
-  int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
+__device__ __forceinline__ void sweep_row(int i, const int32_t* indptr, const int32_t* indices,
+                                          const float* vals, const float* dinv, const float* b,
+                                          const float* x, float* out) {
   float a0 = 0.f, a1 = 0.f, a2 = 0.f;
   const int e = indptr[i + 1];
   for (int j = indptr[i]; j < e; j += kRowUnroll) {
@@ -683,31 +697,68 @@ __global__ __launch_bounds__(256) void k_sweep(int n, const int32_t* __restrict_
   st4(out, i, xi.x + d * (bi.x - a0), xi.y + d * (bi.y - a1), xi.z + d * (bi.z - a2));
 }
 
-// x = dinv .* b
-__global__ __launch_bounds__(256) void k_scale(int n, const float* __restrict__ dinv,
-                                               const float* __restrict__ b, float* __restrict__ x) {
+__global__ __launch_bounds__(256) void k_sweep(int n, const int32_t* __restrict__ indptr,
+                                               const int32_t* __restrict__ indices,
+                                               const float* __restrict__ vals,
+                                               const float* __restrict__ dinv,
+                                               const float* __restrict__ b,
+                                               const float* __restrict__ x, float* __restrict__ out) {
   int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
+  if (i < n) sweep_row(i, indptr, indices, vals, dinv, b, x, out);
+}
+
+// x = dinv .* b
+__device__ __forceinline__ void scale_row(int i, const float* dinv, const float* b, float* x) {
   const float d = dinv[i];
   const float4 bi = ld4(b, i);
   st4(x, i, d * bi.x, d * bi.y, d * bi.z);
 }
 
-// x = Ainv * b on the coarsest level (nc <= kCoarseMax), one block; the inverse stays fp64
-__global__ __launch_bounds__(128) void k_dense_solve(int nc, const double* __restrict__ ainv,
-                                                     const float* __restrict__ b,
-                                                     float* __restrict__ x) {
-  __shared__ double sb[kCoarseMax * 3];
-  for (int t = threadIdx.x; t < nc * 3; t += blockDim.x) sb[t] = double(b[kVecStride * (t / 3) + t % 3]);
-  __syncthreads();
-  for (int t = threadIdx.x; t < nc * 3; t += blockDim.x) {
-    const int i = t / 3, k = t % 3;
-    double s = 0.0;
-    for (int j = 0; j < nc; ++j) s += ainv[size_t(i) * nc + j] * sb[3 * j + k];
-    x[kVecStride * i + k] = float(s);
-  }
-  for (int i = threadIdx.x; i < nc; i += blockDim.x) x[kVecStride * i + 3] = 0.f;
+__global__ __launch_bounds__(256) void k_scale(int n, const float* __restrict__ dinv,
+                                               const float* __restrict__ b, float* __restrict__ x) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) scale_row(i, dinv, b, x);
 }
+
+// x = Ainv * b on the coarsest level (nc <= kCoarseMax) by the first 3 * nc threads of the block
+// (every thread of the block calls it): thread (i, k) adds up row i for column k in four
+// interleaved chains; the inverse is stored transposed, so that a wave's loads are contiguous
+// (one thread per output with a 96-long dependent chain over a row-major inverse: 7.6 us as a
+// kernel of its own, 6.3 us this way — most of it is the launch). The inverse stays fp64.
+__device__ __forceinline__ void dense_solve_block(int nc, const double* ainv_t, const float* b,
+                                                  float* x) {
+  __shared__ double sb[3][kCoarseMax];
+  const int t = threadIdx.x;
+  const int i = t % nc, k = t / nc;
+  if (t < 3 * nc) sb[k][i] = double(b[kVecStride * i + k]);
+  __syncthreads();
+  if (t >= 3 * nc) return;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int j = 0;
+  for (; j + 4 <= nc; j += 4) {
+    s0 += ainv_t[size_t(j) * nc + i] * sb[k][j];
+    s1 += ainv_t[size_t(j + 1) * nc + i] * sb[k][j + 1];
+    s2 += ainv_t[size_t(j + 2) * nc + i] * sb[k][j + 2];
+    s3 += ainv_t[size_t(j + 3) * nc + i] * sb[k][j + 3];
+  }
+  for (; j < nc; ++j) s0 += ainv_t[size_t(j) * nc + i] * sb[k][j];
+  x[kVecStride * i + k] = float((s0 + s1) + (s2 + s3));
+  if (k == 0) x[kVecStride * i + 3] = 0.f;
+}
+
+__global__ __launch_bounds__(3 * kCoarseMax) void k_dense_solve(int nc, const double* __restrict__ ainv_t,
+                                                                const float* __restrict__ b,
+                                                                float* __restrict__ x) {
+  dense_solve_block(nc, ainv_t, b, x);
+}
+
+// (Round 2 experiment, dropped: the levels of <= 4096 / 2048 / 1024 / 512 rows down to the dense
+// solve run by ONE 1024-thread workgroup, level after level with workgroup barriers instead of a
+// launch per level and pass — same row functions, bit-identical results, and no faster: 1933-1972
+// ms of multigrid CG per 20 contractions of the 1 M-point forest against 1955 ms with separate
+// launches. Back-to-back launches on one stream already overlap their launch cost; what a small
+// level costs is its chain of dependent memory round trips, and those are the same inside one
+// workgroup.)
 
 // fp64 [n,3] -> the cycle's fp32 rows
 __global__ __launch_bounds__(256) void k_rows_to_float(int n, const double* __restrict__ a,
@@ -774,8 +825,12 @@ static int coarse_inverse(Ctx* c, const AmgLevel& L, double** d_inv) {
       inv[size_t(i) * n + col] = s / G[size_t(i) * n + i];
     }
   }
+  // stored transposed: k_dense_solve reads element (i, j) at [j * n + i], consecutive threads
+  // consecutive i
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) A[size_t(j) * n + i] = inv[size_t(i) * n + j];
   PQ_TRY(c->arena.get(size_t(n) * n, d_inv));
-  PQ_HIP(hipMemcpyAsync(*d_inv, inv.data(), size_t(n) * n * 8, hipMemcpyHostToDevice, c->stream));
+  PQ_HIP(hipMemcpyAsync(*d_inv, A.data(), size_t(n) * n * 8, hipMemcpyHostToDevice, c->stream));
   PQ_HIP(hipStreamSynchronize(c->stream));
   return 0;
 }
@@ -991,7 +1046,7 @@ static int vcycle_impl(Ctx* c, AmgHierarchy* H, const TV* b, TV* x, double* dot)
     const dim3 g(ceil_div(L.n, 256));
     if (l == nl - 1) {  // (never level 0: hierarchies with a single level are not used)
       if (H->dense_inv) {
-        hipLaunchKernelGGL(k_dense_solve, dim3(1), dim3(128), 0, c->stream, L.n, H->dense_inv, bl, L.xb);
+        hipLaunchKernelGGL(k_dense_solve, dim3(1), dim3(3 * kCoarseMax), 0, c->stream, L.n, H->dense_inv, bl, L.xb);
       } else {  // kTailSweeps (even) l1-Jacobi sweeps, ending in xb
         hipLaunchKernelGGL(k_scale, g, blk, 0, c->stream, L.n, L.dinvf, bl, L.xb);
         for (int s = 0; s < kTailSweeps; s += 2) {

@@ -96,6 +96,9 @@ __global__ __launch_bounds__(256) void k_diag(int n, const int32_t* __restrict__
 // overwrites its array completely, so an iteration is four launches with no bookkeeping kernel.
 struct Scal {
   double rz[2][3 * kPart], pq[2][3 * kPart], rr[2][3 * kPart], bb[3 * kPart];
+  // fp32 loop only: the totals of rz[p], stored by the first kernel that adds them up (block 0)
+  // for the two later kernels that need them again
+  double rz_tot[2][4];
 };
 
 enum Op { OP_A = 0, OP_B = 1 };  // A = wl L L wl + wh^2 ; B = wl L + wh (wl constant along the edges of L)
@@ -743,12 +746,11 @@ __global__ __launch_bounds__(256) void k_update_r_f(int n, const float* __restri
                                                     const float* __restrict__ q,
                                                     float* __restrict__ x, float* __restrict__ r,
                                                     Scal* __restrict__ sc, int par) {
-  double rr[3] = {0, 0, 0}, pqt[3], rzt[3];
+  double rr[3] = {0, 0, 0}, pqt[3];
   float alpha[3];
   part_total3(sc->pq[par], pqt);
-  part_total3(sc->rz[par], rzt);
 #pragma unroll
-  for (int k = 0; k < 3; ++k) alpha[k] = float(pqt[k] != 0.0 ? rzt[k] / pqt[k] : 0.0);
+  for (int k = 0; k < 3; ++k) alpha[k] = float(pqt[k] != 0.0 ? sc->rz_tot[par][k] / pqt[k] : 0.0);
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     const float4 d = ld4(dir, i), qi = ld4(q, i), xi = ld4(x, i), ri = ld4(r, i);
     st4(x, i, xi.x + alpha[0] * d.x, xi.y + alpha[1] * d.y, xi.z + alpha[2] * d.z);
@@ -765,16 +767,27 @@ __global__ __launch_bounds__(256) void k_update_r_f(int n, const float* __restri
 __global__ __launch_bounds__(256) void k_direction_f(int n, const float* __restrict__ z,
                                                      float* __restrict__ dir, Scal* __restrict__ sc,
                                                      int par) {
-  int i = blockIdx.x * 256 + threadIdx.x;
-  double rzo[3], rzn[3];
-  part_total3(sc->rz[par], rzo);
-  part_total3(sc->rz[par ^ 1], rzn);
-  if (i >= n) return;
+  double rzn[3];
+  part_total3(sc->rz[par ^ 1], rzn);  // the cycle's r.z: first use, kept for the next iteration
   float beta[3];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) beta[k] = float(rzo[k] != 0.0 ? rzn[k] / rzo[k] : 0.0);
-  const float4 zi = ld4(z, i), d = ld4(dir, i);
-  st4(dir, i, zi.x + beta[0] * d.x, zi.y + beta[1] * d.y, zi.z + beta[2] * d.z);
+  for (int k = 0; k < 3; ++k) {
+    const double rzo = sc->rz_tot[par][k];
+    beta[k] = float(rzo != 0.0 ? rzn[k] / rzo : 0.0);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 3) sc->rz_tot[par ^ 1][threadIdx.x] = rzn[threadIdx.x];
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {  // reduce_grid
+    const float4 zi = ld4(z, i), d = ld4(dir, i);
+    st4(dir, i, zi.x + beta[0] * d.x, zi.y + beta[1] * d.y, zi.z + beta[2] * d.z);
+  }
+}
+
+// totals of a partial array into tot[0..2] (one block; the start of a solve)
+__global__ __launch_bounds__(256) void k_part_final(const double* __restrict__ part,
+                                                    double* __restrict__ tot) {
+  double t[3];
+  part_total3(part, t);
+  if (threadIdx.x < 3) tot[threadIdx.x] = t[threadIdx.x];
 }
 
 __global__ __launch_bounds__(256) void k_dot3_f(int n, const float* __restrict__ a,
@@ -820,6 +833,7 @@ static int amg_pcg_f32(Ctx* c, int N, const WorkF& w, AmgHierarchy* H, const flo
   const dim3 rgrid(reduce_grid_f(N));  // kernels that end in a reduction
   hipLaunchKernelGGL(k_dot3_f, rgrid, block, 0, c->stream, N, rhs, w.sc->bb);
   PQ_TRY(amg_vcycle_f32(c, H, w.r, w.z, w.sc->rz[0]));
+  hipLaunchKernelGGL(k_part_final, dim3(1), block, 0, c->stream, w.sc->rz[0], w.sc->rz_tot[0]);
   PQ_HIP(hipMemcpyAsync(w.dir, w.z, size_t(N) * kVecStride * 4, hipMemcpyDeviceToDevice, c->stream));
   for (int k = 0; k < 3; ++k) resid[k] = 1.0;
   *iters = 0;
@@ -830,7 +844,7 @@ static int amg_pcg_f32(Ctx* c, int N, const WorkF& w, AmgHierarchy* H, const flo
     }
     hipLaunchKernelGGL(k_update_r_f, rgrid, block, 0, c->stream, N, w.dir, w.q, y, w.r, w.sc, par);
     PQ_TRY(amg_vcycle_f32(c, H, w.r, w.z, w.sc->rz[par ^ 1]));
-    hipLaunchKernelGGL(k_direction_f, grid, block, 0, c->stream, N, w.z, w.dir, w.sc, par);
+    hipLaunchKernelGGL(k_direction_f, rgrid, block, 0, c->stream, N, w.z, w.dir, w.sc, par);
     return 0;
   };
   if (!amg_graphs_enabled()) cache = nullptr;
