@@ -301,3 +301,23 @@ def test_mean_f64_is_numpy_mean_bit_for_bit():
         assert out.value == float(np.mean(v)), n
     out = ctypes.c_double(1.0)
     assert lib.pyqsm_mean_f64(None, 0, ctypes.byref(out)) == 0 and np.isnan(out.value)
+
+
+def test_draw_samples_rows_are_distinct_uniform_and_seeded():
+    """RANSAC hypotheses (pyransac3d draws random.sample(range(n), 3) per iteration, unseeded):
+    the vectorised sampler gives distinct indices, every ordered triple equally often, the same
+    rows for the same seed; method="stdlib" is the literal per-row loop."""
+    import random
+    from pyqsm_amd.math_utils.fit import draw_samples
+    s = draw_samples(5, 120_000, seed=1)
+    assert s.dtype == np.int64 and s.shape == (120_000, 3) and s.min() == 0 and s.max() == 4
+    assert (s[:, 0] != s[:, 1]).all() and (s[:, 0] != s[:, 2]).all() and (s[:, 1] != s[:, 2]).all()
+    _, counts = np.unique(s[:, 0] * 25 + s[:, 1] * 5 + s[:, 2], return_counts=True)
+    assert len(counts) == 60 and counts.min() > 0.9 * 2000 and counts.max() < 1.1 * 2000
+    assert np.array_equal(draw_samples(1000, 64, seed=7), draw_samples(1000, 64, seed=7))
+    assert sorted(draw_samples(3, 1, seed=0)[0]) == [0, 1, 2]
+    rng = random.Random(5)
+    want = np.array([rng.sample(range(50), 3) for _ in range(10)])
+    assert np.array_equal(draw_samples(50, 10, seed=5, method="stdlib"), want)
+    with pytest.raises(ValueError):
+        draw_samples(2, 4)
