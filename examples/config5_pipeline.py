@@ -39,6 +39,9 @@ def main():
                     help="host threads PER GPU that contract trees concurrently (the library keeps "
                          "one stream and arena per thread; a 50 k-point tree alone is latency-bound)")
     ap.add_argument("--gpus", type=int, default=1, help="GPUs of this node to use (0 = all visible)")
+    ap.add_argument("--engine", default="python", help="contraction loop of a group: python or native "
+                                                         "(pyqsm_extract_skeleton, segments in HBM)")
+    ap.add_argument("--batch-workers", type=int, default=4, help="host threads contracting groups")
     ap.add_argument("--group-points", type=int, default=600_000,
                     help="trees are contracted in block-diagonal groups of up to this many points "
                          "(extract_skeleton_batch); 0 = one extract_skeleton call per tree")
@@ -75,7 +78,7 @@ def main():
             share = [pts[t] for t in trees[d::n_gpus]]
             res = extract_skeleton_batch(share, max_iter=args.skeleton_iters, termination_ratio=0.0,
                                          device=d, group_points=args.group_points,
-                                         workers=max(1, min(args.workers, 4)))
+                                         workers=max(1, args.batch_workers), engine=args.engine)
             return [float(np.linalg.norm(r[1], axis=1).mean()) for r in res]
 
         with ThreadPoolExecutor(max_workers=n_gpus) as pool:

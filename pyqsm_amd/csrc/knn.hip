@@ -220,10 +220,17 @@ __global__ __launch_bounds__(256) void k_knn_reg(int n_query, KnnGrid g,
   bool done = false;
   const int rmax_grid = max(g.nx, max(g.ny, g.nz));
   for (int r = 0; r <= kMaxRing && !done; ++r) {
-    for (int dz = -r; dz <= r; ++dz) {
-      const int zz = cz + dz;
-      if (zz < 0 || zz >= g.nz) continue;
-      for (int dy = -r; dy <= r; ++dy) {
+    const int side = 2 * r + 1;
+    for (int t = 0; t < side * side; ++t) {
+      {
+        // rows of the shell; for r = 1 nearest first — the centre row, the four rows that share a
+        // face with it, the four corner rows (codes (dz+1)*3 + (dy+1), four bits each): the sooner
+        // the list holds near points, the fewer of the later candidates pass the k-th-distance
+        // test and have to be inserted. The result does not depend on the order.
+        const int code = r == 1 ? int((0x862075134ull >> (4 * t)) & 15ull) : t;
+        const int dz = code / side - r, dy = code % side - r;
+        const int zz = cz + dz;
+        if (zz < 0 || zz >= g.nz) continue;
         const int yy = cy + dy;
         if (yy < 0 || yy >= g.ny) continue;
         const int row = (zz * g.ny + yy) * g.nx;
