@@ -111,12 +111,22 @@ __device__ __forceinline__ int cell_index(const GridParams& g, double x, double 
 __global__ __launch_bounds__(256) void k_cell_count(const double* __restrict__ xyz, int64_t n,
                                                     GridParams g, int32_t* __restrict__ counts,
                                                     int32_t* __restrict__ cell_tmp,
-                                                    int32_t* __restrict__ rank_tmp) {
+                                                    int32_t* __restrict__ rank_tmp,
+                                                    int32_t* __restrict__ occ_part /*[gridDim.x]*/) {
+  __shared__ int wfirst[4];
   int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x;
-  if (i >= n) return;
-  int c = cell_index(g, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
-  cell_tmp[i] = c;
-  rank_tmp[i] = atomicAdd(&counts[c], 1);
+  bool first = false;
+  if (i < n) {
+    int c = cell_index(g, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
+    cell_tmp[i] = c;
+    const int rank = atomicAdd(&counts[c], 1);
+    rank_tmp[i] = rank;
+    first = rank == 0;  // exactly one point per occupied cell sees an empty counter
+  }
+  const unsigned long long b = __ballot(first);
+  if ((threadIdx.x & 63) == 0) wfirst[threadIdx.x >> 6] = __popcll(b);
+  __syncthreads();
+  if (threadIdx.x == 0) occ_part[blockIdx.x] = (wfirst[0] + wfirst[1]) + (wfirst[2] + wfirst[3]);
 }
 
 __global__ __launch_bounds__(256) void k_cell_scatter(const double* __restrict__ xyz, int64_t n,
@@ -283,8 +293,10 @@ int build_grid(Ctx* c, const double* xyz, int64_t n, double min_cell, int64_t ma
   PQ_HIP(hipMemsetAsync(g->start, 0, (size_t(g->ncell) + 1) * 4, c->stream));
   GridParams gp{g->minx, g->miny, g->minz, g->inv_cell, g->nx, g->ny, g->nz};
   const dim3 grid(ceil_div(n, 256));
+  g->occ_blocks = int(grid.x);
+  PQ_TRY(c->arena.get(size_t(g->occ_blocks), &g->occ_part));
   hipLaunchKernelGGL(k_cell_count, grid, dim3(256), 0, c->stream, xyz, n, gp, g->start, cell_tmp,
-                     rank_tmp);
+                     rank_tmp, g->occ_part);
   PQ_HIP(hipGetLastError());
   PQ_TRY(exclusive_scan_i32(c, g->start, g->ncell + 1));
   hipLaunchKernelGGL(k_cell_scatter, grid, dim3(256), 0, c->stream, xyz, n, g->start, cell_tmp,
@@ -841,6 +853,8 @@ int coarsen_grid(Ctx* c, const DevGrid& fine, int64_t n, int factor, DevGrid* g)
   P.cny = (fine.ny - 2 + factor - 1) / factor + 2;
   P.cnz = (fine.nz - 2 + factor - 1) / factor + 2;
   *g = fine;
+  g->occ_part = nullptr;  // the fine grid's occupancy does not describe this one
+  g->occ_blocks = 0;
   g->nx = P.cnx;
   g->ny = P.cny;
   g->nz = P.cnz;
@@ -868,6 +882,15 @@ int coarsen_grid(Ctx* c, const DevGrid& fine, int64_t n, int factor, DevGrid* g)
 }
 
 int count_occupied(Ctx* c, const DevGrid& g, int64_t* occupied) {
+  if (g.occ_part) {  // left by build_grid's counting pass
+    std::vector<int32_t> h(size_t(g.occ_blocks));
+    PQ_HIP(hipMemcpyAsync(h.data(), g.occ_part, h.size() * 4, hipMemcpyDeviceToHost, c->stream));
+    PQ_HIP(hipStreamSynchronize(c->stream));
+    int64_t t = 0;
+    for (int32_t v : h) t += v;
+    *occupied = t;
+    return 0;
+  }
   int32_t* d = nullptr;
   PQ_TRY(c->arena.get(1, &d));
   PQ_HIP(hipMemsetAsync(d, 0, 4, c->stream));

@@ -21,6 +21,11 @@ struct DevGrid {
   int32_t* order;        // [n] sorted position -> original index
   int32_t* cell_of;      // [n] cell id of each sorted position
   double *sx, *sy, *sz;  // [n] sorted coordinates
+  // build_grid only: per block of its counting pass, the points that were the first of their
+  // cell — their sum is the number of occupied cells (count_occupied), without a pass over
+  // the ncell-long start array
+  int32_t* occ_part = nullptr;
+  int occ_blocks = 0;
 };
 
 // Builds the grid for n points (f64 [n,3], device) with cells of at least
