@@ -1282,7 +1282,12 @@ static int lbc_solve_core(Ctx* c, const DevCsr& L, int64_t n, const double* wl, 
     // attainable accuracy reached. Phase 1 leaves much sooner: its estimate flattens once what is
     // left sits in the modes the Riccati weights over-weight (measured: 1.7e-8 after 23 steps, no
     // better after 35), and those are the plain preconditioner's to finish.
-    if (outer - best_outer >= (phase == 1 ? kRiccatiStall : kOuterStall)) break;
+    static const int ric_stall = [] {  // PYQSM_RICCATI_STALL: tuning knob for kRiccatiStall
+      const char* e = getenv("PYQSM_RICCATI_STALL");
+      const int v = e ? atoi(e) : 0;
+      return v > 0 ? v : kRiccatiStall;
+    }();
+    if (outer - best_outer >= (phase == 1 ? ric_stall : kOuterStall)) break;
     // flexible (Polak-Ribiere) beta: the inner solves are not exact
     double rz_new[3], rzo[3];
     PQ_TRY(dot3_host(c, N, r, z, d_tmp, rz_new));
