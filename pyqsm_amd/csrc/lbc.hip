@@ -988,12 +988,11 @@ __global__ __launch_bounds__(256) void k_scale2(int n, const double* __restrict_
   if (i < n) out[i] = 2.0 * a[i];
 }
 
-static int riccati_mode() {  // PYQSM_RICCATI=0: the preconditioner keeps W_H itself; 2: Riccati whenever W_H varies
-  static const int v = [] {
-    const char* e = getenv("PYQSM_RICCATI");
-    return e ? atoi(e) : 1;
-  }();
-  return v;
+// PYQSM_RICCATI=0: the preconditioner keeps W_H itself; 2: Riccati weights whenever W_H varies;
+// default 1: while W_H is rough (kRiccatiFrac). Read per solve, so that a test can compare the modes.
+static int riccati_mode() {
+  const char* e = getenv("PYQSM_RICCATI");
+  return e ? atoi(e) : 1;
 }
 
 // Device-resident contraction solve.

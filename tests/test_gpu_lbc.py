@@ -125,3 +125,46 @@ def test_block_diagonal_system_with_a_weight_per_block(gpu, n_each):
         xb, _, _, okb = hip.lbc_solve(b[1], wl[lo:hi], wh[lo:hi], P[lo:hi], rtol=1e-9, max_it=500000, device=gpu)
         assert okb and np.abs(xb - x[lo:hi]).max() <= RTOL * np.abs(ref).max()
         lo = hi
+
+
+def test_riccati_weighted_preconditioner_same_solution_fewer_iterations(gpu, monkeypatch):
+    """The preconditioner's Riccati weights (lbc.hip: k_riccati_f) change how
+    fast the outer iteration converges, not what it converges to: on the system of the third
+    contraction of a loop — the first with a rough W_H — the solve with PYQSM_RICCATI=1 agrees
+    with the plain one to the solver's tolerance, both end with ok = True, and it takes fewer
+    iterations; with a uniform W_H the Riccati equation is solved by W_H itself and the two modes
+    return the same bits."""
+    from pyqsm_amd import synth
+    from pyqsm_amd.geometry import skeletonize as sk
+    P = synth.forest(30_000, seed=4)
+    systems = []
+    inner = sk.least_squares_sparse
+
+    def capture(pts, L, laplacian_weighting, positional_weighting, **kw):
+        systems.append((L.copy(), laplacian_weighting.copy(), positional_weighting.copy(), pts.copy()))
+        return inner(pts=pts, L=L, laplacian_weighting=laplacian_weighting,
+                     positional_weighting=positional_weighting, **kw)
+
+    monkeypatch.setattr(sk, "least_squares_sparse", capture)
+    sk.extract_skeleton(P, max_iter=3, termination_ratio=0.0, contraction_factor=3, attraction_factor=3)
+    monkeypatch.undo()
+    assert len(systems) == 3
+    out = {}
+    for step in (0, 2):
+        L, wl, wh, pts = systems[step]
+        for mode in ("0", "1"):
+            monkeypatch.setenv("PYQSM_RICCATI", mode)
+            out[step, mode] = hip.lbc_solve(L, wl, wh, pts, rtol=1e-8, device=gpu)
+        monkeypatch.delenv("PYQSM_RICCATI")
+    x0, it0, _, ok0 = out[0, "0"]
+    x1, it1, _, ok1 = out[0, "1"]
+    assert ok0 and ok1 and it0 == it1 and np.array_equal(x0, x1)          # uniform W_H: F = 0
+    x0, it0, _, ok0 = out[2, "0"]
+    x1, it1, _, ok1 = out[2, "1"]
+    wh = systems[2][2]
+    assert wh.max() / wh.min() > 100.0                                    # rough W_H
+    assert ok0 and ok1
+    scale = np.abs(x0).max()
+    print(f"rough W_H: plain {it0} iterations, Riccati {it1}; difference {np.abs(x0 - x1).max() / scale:.1e}")
+    assert np.abs(x0 - x1).max() <= 1e-6 * scale
+    assert it1 < it0
