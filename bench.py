@@ -360,12 +360,13 @@ def main():
             "mean_shift_m": float(np.linalg.norm(totaln, axis=1).mean()),
             "note": "engine='native': one C-ABI call for the whole loop, no PCIe between the steps"}
         # the three level-0 sparse passes of a multigrid-CG iteration, timed one launch at a time
-        # (profiling level 2) over the first two contractions
+        # (profiling level 2) over all the contractions of the row above
         L0, M0 = skel.point_cloud_laplacian(pts, mollify_factor=1e-6, n_neighbors=20, device=dev)
         pass_bytes = 8.0 * L0.nnz + 36.0 * n
         hip.prof_enable(2, dev)
         hip.prof_reset(dev)
-        skel.extract_skeleton(pts, max_iter=2, termination_ratio=0.0, contraction_factor=3)
+        skel.extract_skeleton(pts, max_iter=args.skel_iters, termination_ratio=0.0, contraction_factor=3,
+                              engine="native")
         passes = {}
         for kname in ("k_bspmv_f", "k_down_l0", "k_up_l0"):
             ms, cnt = hip.prof_get(kname, dev)
@@ -384,7 +385,8 @@ def main():
                          "traffic": None, "passes": passes, "nnz": int(L0.nnz),
                          "note": "level-0 sparse passes (fp32 values, 3 right-hand sides as float4 rows) "
                                  "priced at 8*nnz + 36*N algorithmic bytes each; HIP events around single "
-                                 "launches (profiling level 2) over the first two contractions"}}
+                                 "launches (profiling level 2) over all contractions (the first two alone: "
+                                 "37-38 us per pass, before the cloud has collapsed onto its skeleton)"}}
         if rank == 0 and not args.no_cpu:
             # the reference's own solve (three SciPy spsolve calls, skeletonize.py:167-173) on
             # bounded samples: the first contraction of a 30 k- and a 100 k-point forest
