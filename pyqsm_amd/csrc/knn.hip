@@ -592,6 +592,7 @@ int knn_device(Ctx* c, const double* xyz, int64_t n, int32_t k, int32_t exclude_
     int32_t nf = 0;
     PQ_HIP(hipMemcpyAsync(&nf, fail_count, 4, hipMemcpyDeviceToHost, c->stream));
     PQ_HIP(hipStreamSynchronize(c->stream));
+    if (getenv("PYQSM_KNN_TRACE")) fprintf(stderr, "knn level %d: %d of %d queries stay open (cell %.4g)\n", level, nf, n_query, g.cell);
     if (nf == 0) break;
     // retry the stragglers on a 4x coarser grid
     ProfScope ps(c, "knn_bin");

@@ -115,6 +115,52 @@ __host__ __device__ inline double pseudo_angle(double x, double y) {
   return 2.0 - p;
 }
 
+// ---- stage 1b: tangent planes, one THREAD per point -------------------------------------
+// Covariance of the neighbour offsets (accumulated in neighbour order), its smallest eigenvector,
+// the tangent basis (e1, e2). This used to be the head of k_fans, where all 32 (64) lanes of a
+// point's group ran the same twelve Jacobi sweeps — ~6000 fp64 instructions per wave, most of the
+// kernel's 6.8 ms per million points. Once per point instead of once per lane; the operations and
+// their order are unchanged, so are the bits.
+__global__ __launch_bounds__(256) void k_tangent_planes(int n, int k, const double* __restrict__ xyz,
+                                                        const int32_t* __restrict__ nbr,
+                                                        double* __restrict__ basis /*[n][6]: e1, e2*/) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const double px = xyz[3 * i], py = xyz[3 * i + 1], pz = xyz[3 * i + 2];
+  Sym3 A = {0, 0, 0, 0, 0, 0};
+  for (int l0 = 0; l0 < k; l0 += 4) {  // four neighbours' gathers side by side
+    double x[4], y[4], z[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int nb = l0 + u < k ? nbr[size_t(i) * k + l0 + u] : n;
+      const bool ok = nb < n;  // a missing neighbour contributes a zero offset, as in k_fans
+      x[u] = ok ? xyz[3 * size_t(nb)] - px : 0.0;
+      y[u] = ok ? xyz[3 * size_t(nb) + 1] - py : 0.0;
+      z[u] = ok ? xyz[3 * size_t(nb) + 2] - pz : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (l0 + u >= k) break;
+      A.a00 += x[u] * x[u];
+      A.a01 += x[u] * y[u];
+      A.a02 += x[u] * z[u];
+      A.a11 += y[u] * y[u];
+      A.a12 += y[u] * z[u];
+      A.a22 += z[u] * z[u];
+    }
+  }
+  double nrm[3], e1[3], e2[3];
+  smallest_eigvec(A, nrm);
+  tangent_basis(nrm, e1, e2);
+  double* b = basis + 6 * size_t(i);
+  b[0] = e1[0];
+  b[1] = e1[1];
+  b[2] = e1[2];
+  b[3] = e2[0];
+  b[4] = e2[1];
+  b[5] = e2[2];
+}
+
 // ---- stage 2: local Delaunay fans, one wave per point ----------------------------
 
 __device__ __forceinline__ double bcast(double v, int lane) { return __shfl(v, lane, 64); }
@@ -126,6 +172,7 @@ __device__ __forceinline__ double bcast(double v, int lane) { return __shfl(v, l
 template <int PER>
 __global__ __launch_bounds__(256) void k_fans(int n, int k, const double* __restrict__ xyz,
                                               const int32_t* __restrict__ nbr,
+                                              const double* __restrict__ basis /*k_tangent_planes*/,
                                               int32_t* __restrict__ tri /*[n*k][2]*/,
                                               int32_t* __restrict__ tri_count /*[n]*/) {
   constexpr int G = 64 / PER;  // lanes per point
@@ -147,20 +194,8 @@ __global__ __launch_bounds__(256) void k_fans(int n, int k, const double* __rest
     }
   }
   const bool valid = nb < n;
-  // covariance of the offsets, accumulated in neighbour order (every lane of the group the same)
-  Sym3 A = {0, 0, 0, 0, 0, 0};
-  for (int l = 0; l < k; ++l) {
-    const double x = bcast(dx, gbase + l), y = bcast(dy, gbase + l), z = bcast(dz, gbase + l);
-    A.a00 += x * x;
-    A.a01 += x * y;
-    A.a02 += x * z;
-    A.a11 += y * y;
-    A.a12 += y * z;
-    A.a22 += z * z;
-  }
-  double nrm[3], e1[3], e2[3];
-  smallest_eigvec(A, nrm);
-  tangent_basis(nrm, e1, e2);
+  const double* bs = basis + 6 * size_t(ic);
+  const double e1[3] = {bs[0], bs[1], bs[2]}, e2[3] = {bs[3], bs[4], bs[5]};
   const double u = (dx * e1[0] + dy * e1[1]) + dz * e1[2];
   const double v = (dx * e2[0] + dy * e2[1]) + dz * e2[2];
   const double uu = u * u + v * v;
@@ -913,12 +948,16 @@ int laplacian_device(Ctx* c, const double* d_xyz, int64_t n, const int64_t* seg_
   PQ_HIP(hipMemsetAsync(d_tcount, 0, (size_t(n) + 1) * 4, c->stream));
   {
     ProfScope ps(c, "lap_fans");
+    double* d_basis = nullptr;
+    PQ_TRY(c->arena.get(size_t(n) * 6, &d_basis));
+    hipLaunchKernelGGL(k_tangent_planes, dim3(ceil_div(n, 256)), dim3(256), 0, c->stream, N, k, d_xyz, d_nbr,
+                       d_basis);
     if (k <= 32)
-      hipLaunchKernelGGL(k_fans<2>, dim3(ceil_div(n, 8)), dim3(256), 0, c->stream, N, k, d_xyz, d_nbr, d_tri,
-                         d_tcount);
+      hipLaunchKernelGGL(k_fans<2>, dim3(ceil_div(n, 8)), dim3(256), 0, c->stream, N, k, d_xyz, d_nbr, d_basis,
+                         d_tri, d_tcount);
     else
-      hipLaunchKernelGGL(k_fans<1>, dim3(ceil_div(n, 4)), dim3(256), 0, c->stream, N, k, d_xyz, d_nbr, d_tri,
-                         d_tcount);
+      hipLaunchKernelGGL(k_fans<1>, dim3(ceil_div(n, 4)), dim3(256), 0, c->stream, N, k, d_xyz, d_nbr, d_basis,
+                         d_tri, d_tcount);
     PQ_HIP(hipGetLastError());
   }
   ProfScope ps(c, "lap_assemble");
