@@ -160,8 +160,24 @@ __global__ __launch_bounds__(T) void k_knn(int n_query, const int32_t* __restric
 // acceptance test then works with a slightly stale k-th distance (a superset is buffered);
 // buffers are flushed before every "done" test, so the result is the same list. Measured on the
 // 1 M-point forest, k = 20: see DESIGN.md (k_knn_reg).
-template <int K, int BUF>
+// STRICT: the list is ordered by the distance ALONE (one fp64 compare per slot instead of two plus
+// an index compare: 9 -> 7 vector instructions per slot, and the insertions are two thirds of this
+// kernel: search 1.78 -> 1.25 ms per million points). Exactness is kept by detection, not by the
+// comparison: equal distances INSIDE the list end up in arrival order and are put into index order
+// by a pass at the end (a few instructions unless there are ties); a tie ACROSS the k-th place — a
+// candidate dropped or evicted with the distance of the list's last entry — makes which index
+// belongs to the result depend on what the comparison ignored, so that query is listed in
+// `tie_list` and searched again by the exact variant (STRICT = false over `qlist`). Coordinates
+// quantised to millimetres give a few per cent of such queries, a regular lattice nearly all
+// (then the strict pass is wasted: 1.7x the exact kernel alone).
+template <int K, int BUF, bool STRICT>
 __global__ __launch_bounds__(256) void k_knn_reg(int n_query, KnnGrid g,
+                                                 const int32_t* __restrict__ qlist /*sorted positions
+                                                 to search, or null: all n_query*/,
+                                                 const int32_t* __restrict__ qcount /*length of qlist,
+                                                 on the device*/,
+                                                 int q_min /*a list of at most this many is somebody
+                                                 else's (k_knn_wave): nothing to do*/,
                                                  const int32_t* __restrict__ start,
                                                  const int32_t* __restrict__ order,
                                                  const int32_t* __restrict__ cell_of,
@@ -172,9 +188,18 @@ __global__ __launch_bounds__(256) void k_knn_reg(int n_query, KnnGrid g,
                                                  int32_t* __restrict__ out_idx,
                                                  double* __restrict__ out_d2,
                                                  int32_t* __restrict__ fail_list,
-                                                 int32_t* __restrict__ fail_count) {
-  const int p = blockIdx.x * 256 + threadIdx.x;  // sorted position of this query
-  if (p >= n_query) return;
+                                                 int32_t* __restrict__ fail_count,
+                                                 int32_t* __restrict__ tie_list,
+                                                 int32_t* __restrict__ tie_count) {
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  int p = gid;  // sorted position of this query
+  if (qlist) {
+    const int cnt = *qcount;
+    if (cnt <= q_min || gid >= cnt) return;
+    p = qlist[gid];
+  } else if (p >= n_query) {
+    return;
+  }
   const int self = order[p];
   const double x = sx[p], y = sy[p], z = sz[p];
   const int c = cell_of[p];
@@ -195,18 +220,39 @@ __global__ __launch_bounds__(256) void k_knn_reg(int n_query, KnnGrid g,
     fi[j] = 0x7FFFFFFF;
   }
   int nbuf = 0;
+  // STRICT: the smallest distance at which a candidate was dropped or evicted while equal to the
+  // list's last entry; only if that is still the last entry's distance at the end does the result
+  // depend on an index the comparison did not look at (earlier ties lie beyond the final k-th place)
+  double tie_val = __builtin_inf();
   // sorted insertion of one candidate; (inf, max) is never smaller than a list entry: a no-op
   auto insert = [&](double d, int id) {
-    bool lt_cur = d < bd[K - 1] || (d == bd[K - 1] && id < bi[K - 1]);
+    if constexpr (STRICT) {
+      const double last = bd[K - 1];
+      bool lt_cur = d < last;
+      const bool enters = lt_cur;
+      tie_val = d == last && d < tie_val ? d : tie_val;  // dropped: as far as the list's last entry
 #pragma unroll
-    for (int t = K - 1; t > 0; --t) {
-      const bool lt_prev = d < bd[t - 1] || (d == bd[t - 1] && id < bi[t - 1]);
-      bd[t] = lt_prev ? bd[t - 1] : (lt_cur ? d : bd[t]);
-      bi[t] = lt_prev ? bi[t - 1] : (lt_cur ? id : bi[t]);
-      lt_cur = lt_prev;
+      for (int t = K - 1; t > 0; --t) {
+        const bool lt_prev = d < bd[t - 1];
+        bd[t] = lt_prev ? bd[t - 1] : (lt_cur ? d : bd[t]);
+        bi[t] = lt_prev ? bi[t - 1] : (lt_cur ? id : bi[t]);
+        lt_cur = lt_prev;
+      }
+      bd[0] = lt_cur ? d : bd[0];
+      bi[0] = lt_cur ? id : bi[0];
+      tie_val = enters && last == bd[K - 1] && last < tie_val ? last : tie_val;  // evicted: as far as the new last
+    } else {
+      bool lt_cur = d < bd[K - 1] || (d == bd[K - 1] && id < bi[K - 1]);
+#pragma unroll
+      for (int t = K - 1; t > 0; --t) {
+        const bool lt_prev = d < bd[t - 1] || (d == bd[t - 1] && id < bi[t - 1]);
+        bd[t] = lt_prev ? bd[t - 1] : (lt_cur ? d : bd[t]);
+        bi[t] = lt_prev ? bi[t - 1] : (lt_cur ? id : bi[t]);
+        lt_cur = lt_prev;
+      }
+      bd[0] = lt_cur ? d : bd[0];
+      bi[0] = lt_cur ? id : bi[0];
     }
-    bd[0] = lt_cur ? d : bd[0];
-    bi[0] = lt_cur ? id : bi[0];
   };
   auto flush = [&]() {
 #pragma unroll
@@ -256,7 +302,7 @@ __global__ __launch_bounds__(256) void k_knn_reg(int n_query, KnnGrid g,
               int id = 0x7FFFFFFF;
               if (acc) {
                 id = order[q];
-                acc = d < bd[K - 1] || (d == bd[K - 1] && id < bi[K - 1]);
+                if constexpr (!STRICT) acc = d < bd[K - 1] || (d == bd[K - 1] && id < bi[K - 1]);
               }
               if (acc) {
 #pragma unroll
@@ -292,6 +338,29 @@ __global__ __launch_bounds__(256) void k_knn_reg(int n_query, KnnGrid g,
     if (kth <= safe * safe) done = true;
     if (r >= rmax_grid) done = true;  // the cube already covers the whole grid
   }
+  bool tie = false;
+  if constexpr (STRICT) {
+    // a tie across the k-th place: with something outside the list (k = K) ...
+    tie = k == K && tie_val == bd[K - 1] && tie_val < __builtin_inf();
+    // ... or inside it (lists longer than k)
+#pragma unroll
+    for (int j = 1; j < K; ++j)
+      if (j == k) tie |= bd[j] == bd[j - 1] && bd[j] < __builtin_inf();
+    // equal distances inside the list: arrival order -> index order (bubble passes over the
+    // indices of equal neighbours; no pass finds anything to do unless there are ties)
+    for (int pass = 0; pass < K; ++pass) {
+      bool sw = false;
+#pragma unroll
+      for (int t = 1; t < K; ++t) {
+        const bool c = bd[t] == bd[t - 1] && bi[t] < bi[t - 1];
+        const int lo = c ? bi[t] : bi[t - 1], hi = c ? bi[t - 1] : bi[t];
+        bi[t - 1] = lo;
+        bi[t] = hi;
+        sw |= c;
+      }
+      if (__ballot(sw) == 0ull) break;
+    }
+  }
   // one atomic per wave for the queries that stay open (per lane it was ~10^4 atomics on one
   // address per million points)
   const bool open = !done && !last_level;
@@ -304,6 +373,19 @@ __global__ __launch_bounds__(256) void k_knn_reg(int n_query, KnnGrid g,
     if (open) {
       fail_list[base + __popcll(ob & ((1ull << lane) - 1ull))] = self;
       return;
+    }
+  }
+  if constexpr (STRICT) {  // the queries whose result hangs on a tie: again, by the exact variant
+    const unsigned long long tb = __ballot(tie);
+    if (tb != 0) {
+      const int lane = threadIdx.x & 63, lead = __ffsll(tb) - 1;
+      int base = 0;
+      if (lane == lead) base = atomicAdd(tie_count, __popcll(tb));
+      base = __shfl(base, lead, 64);
+      if (tie) {
+        tie_list[base + __popcll(tb & ((1ull << lane) - 1ull))] = p;
+        return;
+      }
     }
   }
 #pragma unroll
@@ -323,29 +405,59 @@ static int knn_buffer_slots() {  // PYQSM_KNN_BUF=0: direct insertion (the round
   return v;
 }
 
+__global__ void k_knn_wave(int n_query, const int32_t* __restrict__ n_ptr, int n_max,
+                           const int32_t* __restrict__ query_list, const int32_t* __restrict__ pos_of,
+                           KnnGrid g, const int32_t* __restrict__ start, const int32_t* __restrict__ order,
+                           const int32_t* __restrict__ cell_of, const double* __restrict__ sx,
+                           const double* __restrict__ sy, const double* __restrict__ sz, int k,
+                           int exclude_self, int n_total, int last_level, int max_ring,
+                           int32_t* __restrict__ out_idx, double* __restrict__ out_d2,
+                           int32_t* __restrict__ fail_list, int32_t* __restrict__ fail_count);
+
+static bool knn_strict() {  // PYQSM_KNN_STRICT=0: the exact comparison in the first pass already
+  static const bool v = [] {
+    const char* e = getenv("PYQSM_KNN_STRICT");
+    return !(e && e[0] == '0');
+  }();
+  return v;
+}
+
+// tie_list [n] / tie_count [1] (zeroed by the caller): scratch of the strict pass.
 template <int K>
 static int launch_knn_reg(Ctx* c, int n, const DevGrid& g, int k, int excl, int last, int32_t* idx,
-                          double* d2, int32_t* fail_list, int32_t* fail_count) {
+                          double* d2, int32_t* fail_list, int32_t* fail_count, int32_t* tie_list,
+                          int32_t* tie_count) {
   KnnGrid kg{g.nx, g.ny, g.nz, g.cell};
   const dim3 grid(ceil_div(n, 256)), blk(256);
-  switch (knn_buffer_slots()) {
-    case 0:
-      hipLaunchKernelGGL((k_knn_reg<K, 0>), grid, blk, 0, c->stream, n, kg, g.start, g.order, g.cell_of, g.sx,
-                         g.sy, g.sz, k, excl, n, last, idx, d2, fail_list, fail_count);
-      break;
-    case 2:
-      hipLaunchKernelGGL((k_knn_reg<K, 2>), grid, blk, 0, c->stream, n, kg, g.start, g.order, g.cell_of, g.sx,
-                         g.sy, g.sz, k, excl, n, last, idx, d2, fail_list, fail_count);
-      break;
-    case 8:
-      hipLaunchKernelGGL((k_knn_reg<K, 8>), grid, blk, 0, c->stream, n, kg, g.start, g.order, g.cell_of, g.sx,
-                         g.sy, g.sz, k, excl, n, last, idx, d2, fail_list, fail_count);
-      break;
-    default:
-      hipLaunchKernelGGL((k_knn_reg<K, 4>), grid, blk, 0, c->stream, n, kg, g.start, g.order, g.cell_of, g.sx,
-                         g.sy, g.sz, k, excl, n, last, idx, d2, fail_list, fail_count);
+  const int32_t* none = nullptr;
+  if (knn_buffer_slots() == 0) {
+    hipLaunchKernelGGL((k_knn_reg<K, 0, false>), grid, blk, 0, c->stream, n, kg, none, none, 0, g.start, g.order,
+                       g.cell_of, g.sx, g.sy, g.sz, k, excl, n, last, idx, d2, fail_list, fail_count, tie_list,
+                       tie_count);
+  } else if (!knn_strict()) {
+    hipLaunchKernelGGL((k_knn_reg<K, 4, false>), grid, blk, 0, c->stream, n, kg, none, none, 0, g.start, g.order,
+                       g.cell_of, g.sx, g.sy, g.sz, k, excl, n, last, idx, d2, fail_list, fail_count, tie_list,
+                       tie_count);
+  } else {
+    hipLaunchKernelGGL((k_knn_reg<K, 4, true>), grid, blk, 0, c->stream, n, kg, none, none, 0, g.start, g.order,
+                       g.cell_of, g.sx, g.sy, g.sz, k, excl, n, last, idx, d2, fail_list, fail_count, tie_list,
+                       tie_count);
+    // The queries whose result hung on a tie, by the exact comparison: a WAVE per query (a lane per
+    // query would be one long-running wave of 64 unrelated walks — 0.5 ms for 238 such queries of
+    // a millimetre-quantised million points; this way they cost 20 us). Their number stays on the
+    // device; the waves of a fixed grid stride over them. A cloud on a regular lattice ties nearly
+    // everywhere (760 k of a million queries): past n / 16 the list goes to the per-lane kernel
+    // with the exact comparison instead (both launches are issued, one of them finds nothing to do).
+    const int many = n / 16;
+    hipLaunchKernelGGL(k_knn_wave, dim3(unsigned(std::min<int64_t>(ceil_div(n, 4), 8192))), blk, 0, c->stream, n,
+                       static_cast<const int32_t*>(tie_count), many, static_cast<const int32_t*>(tie_list),
+                       static_cast<const int32_t*>(nullptr), kg, g.start, g.order, g.cell_of, g.sx, g.sy, g.sz, k,
+                       excl, n, last, kMaxRing, idx, d2, fail_list, fail_count);
+    hipLaunchKernelGGL((k_knn_reg<K, 4, false>), grid, blk, 0, c->stream, n, kg,
+                       static_cast<const int32_t*>(tie_list), static_cast<const int32_t*>(tie_count), many,
+                       g.start, g.order, g.cell_of, g.sx, g.sy, g.sz, k, excl, n, last, idx, d2, fail_list,
+                       fail_count, tie_list, tie_count);
   }
-
   PQ_HIP(hipGetLastError());
   return 0;
 }
@@ -355,7 +467,12 @@ static int launch_knn_reg(Ctx* c, int n, const DevGrid& g, int k, int excl, int 
 // The sorted best-k list lives in registers, element j in lane j; an insertion
 // is a ballot (position) plus one lane shift.
 __global__ __launch_bounds__(256) void k_knn_wave(int n_query,
-                                                  const int32_t* __restrict__ query_list,
+                                                  const int32_t* __restrict__ n_ptr /*the number of
+                                                  queries on the device, or null: n_query*/,
+                                                  int n_max /*with n_ptr: more queries than this are
+                                                  somebody else's (k_knn_reg over the list)*/,
+                                                  const int32_t* __restrict__ query_list /*original
+                                                  indices (pos_of given) or sorted positions*/,
                                                   const int32_t* __restrict__ pos_of, KnnGrid g,
                                                   const int32_t* __restrict__ start,
                                                   const int32_t* __restrict__ order,
@@ -369,9 +486,10 @@ __global__ __launch_bounds__(256) void k_knn_wave(int n_query,
                                                   int32_t* __restrict__ fail_list,
                                                   int32_t* __restrict__ fail_count) {
   const int lane = threadIdx.x & 63;
-  const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (qi >= n_query) return;  // whole wave
-  const int p = query_list ? pos_of[query_list[qi]] : qi;
+  int nq = n_ptr ? *n_ptr : n_query;
+  if (n_ptr && nq > n_max) nq = 0;
+  for (int qi = blockIdx.x * 4 + (threadIdx.x >> 6); qi < nq; qi += gridDim.x * 4) {  // whole waves
+  const int p = query_list ? (pos_of ? pos_of[query_list[qi]] : query_list[qi]) : qi;
   const int self = order[p];
   const double x = sx[p], y = sy[p], z = sz[p];
   const int c = cell_of[p];
@@ -464,11 +582,12 @@ __global__ __launch_bounds__(256) void k_knn_wave(int n_query,
   }
   if (!done && !last_level) {
     if (lane == 0) fail_list[atomicAdd(fail_count, 1)] = self;
-    return;
+    continue;
   }
   if (lane < k) {
     out_idx[size_t(self) * k + lane] = lane < have ? bi : n_total;
     out_d2[size_t(self) * k + lane] = lane < have ? bd : __builtin_inf();
+  }
   }
 }
 
@@ -550,6 +669,10 @@ int knn_device(Ctx* c, const double* xyz, int64_t n, int32_t k, int32_t exclude_
   PQ_TRY(c->arena.get(size_t(n), &fail_a));
   PQ_TRY(c->arena.get(size_t(n), &fail_b));
   PQ_TRY(c->arena.get(1, &fail_count));
+  int32_t *tie_list, *tie_count;
+  PQ_TRY(c->arena.get(size_t(n), &tie_list));
+  PQ_TRY(c->arena.get(1, &tie_count));
+  PQ_HIP(hipMemsetAsync(tie_count, 0, 4, c->stream));
   int n_query = N;
   const int32_t* list = nullptr;
   for (int level = 0;; ++level) {
@@ -563,19 +686,19 @@ int knn_device(Ctx* c, const double* xyz, int64_t n, int32_t k, int32_t exclude_
         // list length = k rounded up to a multiple of 4: every slot is ~11 instructions per
         // insertion, and slots beyond k loosen the acceptance test
         switch ((k + 3) / 4) {
-          case 1: PQ_TRY(launch_knn_reg<4>(c, N, g, k, exclude_self, last, idx, d2, fl, fail_count)); break;
-          case 2: PQ_TRY(launch_knn_reg<8>(c, N, g, k, exclude_self, last, idx, d2, fl, fail_count)); break;
-          case 3: PQ_TRY(launch_knn_reg<12>(c, N, g, k, exclude_self, last, idx, d2, fl, fail_count)); break;
-          case 4: PQ_TRY(launch_knn_reg<16>(c, N, g, k, exclude_self, last, idx, d2, fl, fail_count)); break;
-          case 5: PQ_TRY(launch_knn_reg<20>(c, N, g, k, exclude_self, last, idx, d2, fl, fail_count)); break;
-          case 6: PQ_TRY(launch_knn_reg<24>(c, N, g, k, exclude_self, last, idx, d2, fl, fail_count)); break;
-          case 7: PQ_TRY(launch_knn_reg<28>(c, N, g, k, exclude_self, last, idx, d2, fl, fail_count)); break;
-          default: PQ_TRY(launch_knn_reg<32>(c, N, g, k, exclude_self, last, idx, d2, fl, fail_count)); break;
+          case 1: PQ_TRY(launch_knn_reg<4>(c, N, g, k, exclude_self, last, idx, d2, fl, fail_count, tie_list, tie_count)); break;
+          case 2: PQ_TRY(launch_knn_reg<8>(c, N, g, k, exclude_self, last, idx, d2, fl, fail_count, tie_list, tie_count)); break;
+          case 3: PQ_TRY(launch_knn_reg<12>(c, N, g, k, exclude_self, last, idx, d2, fl, fail_count, tie_list, tie_count)); break;
+          case 4: PQ_TRY(launch_knn_reg<16>(c, N, g, k, exclude_self, last, idx, d2, fl, fail_count, tie_list, tie_count)); break;
+          case 5: PQ_TRY(launch_knn_reg<20>(c, N, g, k, exclude_self, last, idx, d2, fl, fail_count, tie_list, tie_count)); break;
+          case 6: PQ_TRY(launch_knn_reg<24>(c, N, g, k, exclude_self, last, idx, d2, fl, fail_count, tie_list, tie_count)); break;
+          case 7: PQ_TRY(launch_knn_reg<28>(c, N, g, k, exclude_self, last, idx, d2, fl, fail_count, tie_list, tie_count)); break;
+          default: PQ_TRY(launch_knn_reg<32>(c, N, g, k, exclude_self, last, idx, d2, fl, fail_count, tie_list, tie_count)); break;
         }
       } else if (level > 0 && k <= 64) {
         KnnGrid kg{g.nx, g.ny, g.nz, g.cell};
         hipLaunchKernelGGL(k_knn_wave, dim3(ceil_div(n_query, 4)), dim3(256), 0, c->stream, n_query,
-                           list, pos_of, kg, g.start, g.order, g.cell_of, g.sx, g.sy, g.sz, k,
+                           static_cast<const int32_t*>(nullptr), 0, list, pos_of, kg, g.start, g.order, g.cell_of, g.sx, g.sy, g.sz, k,
                            exclude_self, N, last, ring, idx, d2, fl, fail_count);
         PQ_HIP(hipGetLastError());
       } else if (k <= 48)
@@ -592,6 +715,11 @@ int knn_device(Ctx* c, const double* xyz, int64_t n, int32_t k, int32_t exclude_
     int32_t nf = 0;
     PQ_HIP(hipMemcpyAsync(&nf, fail_count, 4, hipMemcpyDeviceToHost, c->stream));
     PQ_HIP(hipStreamSynchronize(c->stream));
+    if (level == 0 && getenv("PYQSM_KNN_TRACE")) {
+      int32_t nt = 0;
+      PQ_HIP(hipMemcpy(&nt, tie_count, 4, hipMemcpyDeviceToHost));
+      fprintf(stderr, "knn level 0: %d queries searched again for a tie at the k-th place\n", nt);
+    }
     if (getenv("PYQSM_KNN_TRACE")) fprintf(stderr, "knn level %d: %d of %d queries stay open (cell %.4g)\n", level, nf, n_query, g.cell);
     if (nf == 0) break;
     // retry the stragglers on a 4x coarser grid

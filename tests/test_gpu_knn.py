@@ -79,3 +79,17 @@ def test_randomised_differential(gpu):
         idx0, d20 = oracle.knn(P, k, excl)
         assert np.array_equal(d2, d20), (case, n, k, excl)
         assert np.array_equal(idx, idx0), (case, n, k, excl)
+
+
+@pytest.mark.parametrize("k", [20, 21, 30])
+def test_quantised_coordinates_have_ties_at_the_kth_place(gpu, k):
+    """Coordinates on a 5 mm grid (a LAS file holds scaled integers): many squared distances coincide,
+    some of them across the k-th place — the case the strict-order first pass of k_knn_reg hands
+    to its exact second pass. Indices and distances equal the oracle's (ties by index)."""
+    P = np.round(synth.forest(40_000, seed=12) * 200.0) / 200.0          # 5 mm grid
+    idx, d2 = hip.knn(P, k, True, device=gpu)
+    idx0, d20 = oracle.knn(P, k, True)
+    tied = float((d20[:, 1:] == d20[:, :-1]).any(axis=1).mean())
+    print(f"k={k}: {tied:.1%} of the queries have equal distances among their neighbours")
+    assert tied > 0.01
+    assert np.array_equal(d2, d20) and np.array_equal(idx, idx0)
