@@ -37,8 +37,13 @@ static constexpr int kMaxRing = 3;
 // The (wave-per-query) retries may walk this many shells: what is still open there are
 // outliers, and one more 4x coarsening instead would make those next to a tree scan whole
 // stems (a point 0.7 m from a trunk: 27 cells of 0.8 m; 4 such queries took 1.25 ms on the
-// 1 M-point forest). From the first retry level on: 1.05 -> 0.83 ms for both levels.
-static constexpr int kWideRing = 8;
+// 1 M-point forest). From the first retry level on: 1.05 -> 0.83 ms for both levels with 8 shells.
+// With 16 the first retry level finishes every outlier of the forest (1 % noise up to 5 m from a
+// stem) and the second one — a coarsening of the grid and a launch whose duration is one long wave,
+// 0.32 + 0.06 ms even for a single query — does not happen: retries 0.83 -> 0.38 ms. A query that
+// does walk all 16 shells looks up 13 000 row segments (200 rounds of 64), about what a launch
+// of the next level costs. PYQSM_KNN_WIDE overrides.
+static constexpr int kWideRing = 16;
 static constexpr int kMaxK = 192;
 
 struct KnnGrid {
@@ -676,7 +681,8 @@ int knn_device(Ctx* c, const double* xyz, int64_t n, int32_t k, int32_t exclude_
   int n_query = N;
   const int32_t* list = nullptr;
   for (int level = 0;; ++level) {
-    const int ring = level >= 1 && k <= 64 ? kWideRing : kMaxRing;
+    static const int wide = [] { const char* e = getenv("PYQSM_KNN_WIDE"); return e ? atoi(e) : kWideRing; }();
+    const int ring = level >= 1 && k <= 64 ? wide : kMaxRing;
     const int last = (g.nx - 2 <= ring && g.ny - 2 <= ring && g.nz - 2 <= ring) ? 1 : 0;
     PQ_HIP(hipMemsetAsync(fail_count, 0, 4, c->stream));
     {
