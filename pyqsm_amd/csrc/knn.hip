@@ -634,9 +634,9 @@ int knn_device(Ctx* c, const double* xyz, int64_t n, int32_t k, int32_t exclude_
   // rebuild is allowed if the sorted grid misses the target by more than 2.5x.
   DevGrid g;
   const int64_t max_cells = int64_t(1) << 28;
+  double box[6];
   {
     ProfScope ps(c, "knn_bin");
-    double box[6];
     PQ_TRY(cloud_bbox(c, xyz, n, box, box + 3));
     double ext = std::max(box[3] - box[0], std::max(box[4] - box[1], box[5] - box[2]));
     if (!(ext > 0)) ext = 1.0;
@@ -733,8 +733,15 @@ int knn_device(Ctx* c, const double* xyz, int64_t n, int32_t k, int32_t exclude_
     list = (level & 1) ? fail_b : fail_a;
     n_query = nf;
     {
+      // Deriving the coarse grid from the fine one reads the fine grid's whole cell array (95 M
+      // cells for a million points at k = 20: 0.22 ms); binning the points again at the coarse edge
+      // touches 1.5 M cells (0.12 ms). The order inside a cell does not matter to a search. Small
+      // fine grids (the later levels) keep the pyramid: no atomics, a few microseconds.
       DevGrid coarse;
-      PQ_TRY(coarsen_grid(c, g, n, 4, &coarse));
+      if (g.ncell > (int64_t(1) << 22))
+        PQ_TRY(build_grid(c, xyz, n, g.cell * 4.0, max_cells, &coarse, box));
+      else
+        PQ_TRY(coarsen_grid(c, g, n, 4, &coarse));
       g = coarse;
     }
     if (!pos_of) PQ_TRY(c->arena.get(size_t(n), &pos_of));
