@@ -493,7 +493,8 @@ __global__ __launch_bounds__(256) void k_knn_wave(int n_query,
   const int lane = threadIdx.x & 63;
   int nq = n_ptr ? *n_ptr : n_query;
   if (n_ptr && nq > n_max) nq = 0;
-  for (int qi = blockIdx.x * 4 + (threadIdx.x >> 6); qi < nq; qi += gridDim.x * 4) {  // whole waves
+  const int wpb = int(blockDim.x) >> 6;  // waves per block
+  for (int qi = blockIdx.x * wpb + (threadIdx.x >> 6); qi < nq; qi += gridDim.x * wpb) {  // whole waves
   const int p = query_list ? (pos_of ? pos_of[query_list[qi]] : query_list[qi]) : qi;
   const int self = order[p];
   const double x = sx[p], y = sy[p], z = sz[p];
@@ -703,6 +704,8 @@ int knn_device(Ctx* c, const double* xyz, int64_t n, int32_t k, int32_t exclude_
         }
       } else if (level > 0 && k <= 64) {
         KnnGrid kg{g.nx, g.ny, g.nz, g.cell};
+        // (one or two waves per block instead of four: no difference — the launch lasts as long as its
+        // longest waves, 0.34 ms for the forest's 9 864 outliers)
         hipLaunchKernelGGL(k_knn_wave, dim3(ceil_div(n_query, 4)), dim3(256), 0, c->stream, n_query,
                            static_cast<const int32_t*>(nullptr), 0, list, pos_of, kg, g.start, g.order, g.cell_of, g.sx, g.sy, g.sz, k,
                            exclude_self, N, last, ring, idx, d2, fl, fail_count);
