@@ -618,8 +618,13 @@ __global__ __launch_bounds__(256) void k_flip_seed(int H, const double* __restri
   if (cand) list[slot] = h;
 }
 
-// Round part 1: every candidate of the list claims its two faces and their four outer
-// neighbours; the claim carries the round in its upper half, so claims never need clearing.
+// Round part 1: every candidate of the list claims its TWO faces; the claim carries the round in
+// its upper half, so claims never need clearing. (Round 1 claimed the four outer neighbours as
+// well — six atomics per candidate — and a flip needed all six. But a flip rewrites its two faces
+// and ONE link slot in each outer neighbour, the slot of the shared edge: two flips that merely
+// share an outer neighbour touch different slots of it and do not conflict. What must not happen
+// is a flip next to a face that is itself being rewritten, i.e. two candidates whose quads share
+// an edge; k_flip_apply settles those by priority with four plain loads.)
 // Priority of a candidate within its round: a bijective hash of the half-edge id. With the id
 // itself, a strip of k adjacent candidates flips one per round (ids grow along the mesh):
 // ~450 rounds on a contracted 1 M-point cloud; hashed, the local maxima are spread out and
@@ -647,14 +652,11 @@ __global__ __launch_bounds__(256) void k_flip_claim(const int32_t* __restrict__ 
     const unsigned long long pr = stamp | flip_priority(h);
     atomicMax(&claim[q.f], pr);
     atomicMax(&claim[q.g], pr);
-    atomicMax(&claim[fn[3 * size_t(q.f) + nx3(q.c)] / 3], pr);
-    atomicMax(&claim[fn[3 * size_t(q.f) + pv3(q.c)] / 3], pr);
-    atomicMax(&claim[fn[3 * size_t(q.g) + nx3(q.d)] / 3], pr);
-    atomicMax(&claim[fn[3 * size_t(q.g) + pv3(q.d)] / 3], pr);
   }
 }
 
-// Round part 2: a candidate that owns all six faces flips its edge.
+// Round part 2: a candidate that owns its two faces and outranks every claim on the four outer
+// neighbours flips its edge.
 //   before: f = (a, b, k) with edge c = a->b,   g = (b, a, l) with edge d = b->a
 //   after:  f = (a, l, k),  g = (b, k, l)       (new edge l->k in f, k->l in g)
 // A candidate that lost stays on the list; a flip puts its five edges on it.
@@ -680,7 +682,7 @@ __global__ __launch_bounds__(256) void k_flip_apply(const int32_t* __restrict__ 
     const int h = list[i];
     const int f = h / 3, c = h % 3;
     const unsigned long long pr = stamp | flip_priority(h);
-    // f and g first: while both are ours nobody else touches their links
+    // f and g first: while both are ours nobody else rewrites them
     bool mine = claim[f] == pr;
     int g = 0, d = 0;
     if (mine) {
@@ -695,8 +697,15 @@ __global__ __launch_bounds__(256) void k_flip_apply(const int32_t* __restrict__ 
       n_ka = fn[3 * size_t(f) + pv3(c)];
       n_al = fn[3 * size_t(g) + nx3(d)];
       n_lb = fn[3 * size_t(g) + pv3(d)];
-      mine = claim[n_bk / 3] == pr && claim[n_ka / 3] == pr && claim[n_al / 3] == pr &&
-             claim[n_lb / 3] == pr;
+      // an outer neighbour is either one of our own two faces (glued copies of the cover) or must
+      // not be claimed this round by a candidate of higher priority: of two candidates whose quads
+      // share an edge each sees the other's claim on that neighbour, and exactly one yields.
+      // (Older claims carry a smaller round stamp and compare lower.)
+      auto free_of = [&](int code) {
+        const int h2 = code / 3;
+        return h2 == f || h2 == g || claim[h2] < pr;
+      };
+      mine = free_of(n_bk) && free_of(n_ka) && free_of(n_al) && free_of(n_lb);
     }
     if (!mine) {
       push[np++] = h;
