@@ -356,6 +356,26 @@ int pyqsm_extract_skeleton(const double* xyz, int64_t n, const int64_t* seg_star
                            int32_t* solve_iters, double* solve_resid, uint8_t* solve_ok,
                            int32_t* n_solves, int32_t device);
 
+/* ---- filters in front of the oriented bounding box's convex hull ----------------- */
+/*
+ * pyQSM/geometry/skeletonize.py:240-241 clamps the contracted points into
+ * pcd.get_oriented_bounding_box().get_min_bound() / get_max_bound(); Open3D builds that box from
+ * a PCA of the convex hull's vertices. Qhull over every point of a scan is 0.3 s per million
+ * points; these two calls cut its input down to ~1 % without changing the hull:
+ *   pyqsm_extreme_points: idx i64 [n_dirs] = the point with the largest x . dirs[d] (dirs f64
+ *   [n_dirs,3]; lowest index on ties);
+ *   pyqsm_outside_halfspaces: eq f64 [n_planes,4] = (a, o) of half-spaces a . x + o <= 0 (the
+ *   facets of a small polytope whose corners are points of the cloud, scipy.spatial.ConvexHull
+ *   .equations); idx i64 [capacity n] receives, ascending, every i with a . x_i + o >= -margin for
+ *   some plane — the points that are not strictly inside — and *count their number. A point
+ *   strictly inside such a polytope is strictly inside the cloud's hull, so the hull of the
+ *   listed points has the same vertices. At most 256 planes.
+ */
+int pyqsm_extreme_points(const double* xyz, int64_t n, const double* dirs, int32_t n_dirs,
+                         int64_t* idx, int32_t device);
+int pyqsm_outside_halfspaces(const double* xyz, int64_t n, const double* eq, int32_t n_planes,
+                             double margin, int64_t* idx, int64_t* count, int32_t device);
+
 /*
  * Host-side helper of that loop, exported so that it can be checked without a GPU: the mean of
  * v[0..n) with NumPy's summation order (pairwise in blocks of 128 with eight accumulators, one

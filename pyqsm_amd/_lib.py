@@ -74,6 +74,8 @@ SIGNATURES = {
                                               ctypes.POINTER(vp), ctypes.POINTER(vp),
                                               ctypes.POINTER(vp), vp, i32]),
     "pyqsm_mean_f64": (ctypes.c_int, [vp, i64, ctypes.POINTER(dbl)]),
+    "pyqsm_extreme_points": (ctypes.c_int, [vp, i64, vp, i32, vp, i32]),
+    "pyqsm_outside_halfspaces": (ctypes.c_int, [vp, i64, vp, i32, dbl, vp, ctypes.POINTER(i64), i32]),
 }
 
 _lib = None

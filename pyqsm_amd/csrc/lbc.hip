@@ -1091,6 +1091,7 @@ static int lbc_solve_core(Ctx* c, const DevCsr& L, int64_t n, const double* wl, 
   // ---- Riccati weights for B (k_riccati_f) -------------------------------------------------------
   int riccati_its = 0;
   if (amg && riccati_mode() != 0) {
+    ProfScope psr(c, "lbc_riccati");
     double *wt, *wj, *negf, *w2, *delta;
     PQ_TRY(c->arena.get(size_t(n), &wt));
     PQ_TRY(c->arena.get(size_t(n), &wj));
@@ -1255,7 +1256,10 @@ static int lbc_solve_core(Ctx* c, const DevCsr& L, int64_t n, const double* wl, 
     if (judge() != 0) return fail(PYQSM_EHIP, "contraction solve: non-finite preconditioned residual");
     return 0;
   };
-  if (!done) PQ_TRY(restart());
+  if (!done) {
+    ProfScope ps0(c, "lbc_first_precond");
+    PQ_TRY(restart());
+  }
   for (;;) {
   while (!done && outer < kOuterMaxIt && total_inner < max_it) {
     ProfScope ps(c, "lbc_outer_iter");
@@ -1418,6 +1422,7 @@ __global__ __launch_bounds__(256) void k_perm_back(int n, const int32_t* __restr
 int lbc_solve_device(Ctx* c, const DevCsr& L, int64_t n, const double* wl, bool wl_edge_const,
                      const double* wh, const double* pts, double rtol, int32_t max_it, double* x,
                      int32_t* iters, double resid[3]) {
+  ProfScope pst(c, "lbc_solve_total");
   const char* pe = getenv("PYQSM_LBC_SORT");
   if (!wl_edge_const || n < 4096 || (pe && pe[0] == '0'))
     return lbc_solve_core(c, L, n, wl, wl_edge_const, wh, pts, rtol, max_it, x, iters, resid);

@@ -128,17 +128,40 @@ def set_amplification(step_wise_contraction_amplification, num_pcd_points, termi
     return termination_ratio, contraction_factor
 
 
-def oriented_bounds(pts):
+_HULL_DIRS = np.array([[x, y, z] for x in (-1, 0, 1) for y in (-1, 0, 1) for z in (-1, 0, 1)
+                       if (x, y, z) != (0, 0, 0)], dtype=np.float64)
+
+
+def _hull_vertices(pts, device=None):
+    """Indices (ascending) of the convex hull's vertices — ``ConvexHull(pts).vertices``. With a
+    ``device`` and a large cloud Qhull only sees the points that are not strictly inside the
+    polytope of the cloud's extreme points along 26 directions (``pyqsm_extreme_points`` /
+    ``pyqsm_outside_halfspaces``: ~1 % of a scan): same vertices, a twentieth of the time."""
+    from scipy.spatial import ConvexHull
+    if device is None or len(pts) < 20_000:
+        return ConvexHull(pts).vertices
+    seed = np.unique(hip.extreme_points(pts, _HULL_DIRS, device=device))
+    try:
+        inner = ConvexHull(pts[seed])
+    except Exception:                       # the extreme points are coplanar: no filter
+        return ConvexHull(pts).vertices
+    margin = 1e-9 * float(np.abs(pts).max())
+    cand = hip.outside_halfspaces(pts, inner.equations, margin, device=device)
+    return cand[ConvexHull(pts[cand]).vertices]      # in 3-D Qhull lists vertices in input order
+
+
+def oriented_bounds(pts, device=None):
     """Axis-aligned min / max of the 8 corners of the PCA-oriented bounding box of
     the convex hull — what ``pcd.get_oriented_bounding_box().get_min_bound() /
     get_max_bound()`` yield at skeletonize.py:240-241 (Open3D builds the box from a
     PCA of the hull vertices). Falls back to the plain bounding box for clouds
-    that have no 3-D hull."""
+    that have no 3-D hull. ``device``: see :func:`_hull_vertices` (same result)."""
     pts = np.asarray(pts, dtype=np.float64)
     try:
-        from scipy.spatial import ConvexHull
-        hull_pts = pts[ConvexHull(pts).vertices]
-    except Exception:
+        hull_pts = pts[_hull_vertices(pts, device)]
+    except Exception as e:
+        if type(e).__name__ != "QhullError" and not isinstance(e, ValueError):
+            raise
         return pts.min(axis=0), pts.max(axis=0)
     mean = hull_pts.mean(axis=0)
     cov = np.cov((hull_pts - mean).T, bias=True)
@@ -183,7 +206,7 @@ def extract_skeleton(pcd, moll=_SK["moll"], n_neighbors=_SK["n_neighbors"],
     if engine == "native":
         if laplacian is not None or debug or cmag_save_file:
             raise ValueError("engine='native' does not take a laplacian hook, debug or cmag_save_file")
-        lo, hi = oriented_bounds(pts)                                      # :240-241
+        lo, hi = oriented_bounds(pts, device=device)                       # :240-241
         out, total, steps, n_steps, slog = hip.extract_skeleton(
             pts, lo, hi, n_neighbors, moll, max_iter, termination_ratio, contraction_factor,
             attraction_factor, max_contraction, max_attraction, SOLVER_RTOL, SOLVER_MAX_IT,
@@ -197,7 +220,7 @@ def extract_skeleton(pcd, moll=_SK["moll"], n_neighbors=_SK["n_neighbors"],
     if engine != "python":
         raise ValueError("engine must be 'python' or 'native'")
     solve_log = []
-    allowed_range = oriented_bounds(pts)                               # :240-241
+    allowed_range = oriented_bounds(pts, device=device)                # :240-241
     lo, hi = np.asarray(allowed_range[0]), np.asarray(allowed_range[1])
     if laplacian is None:
         def laplacian(p):
@@ -293,7 +316,7 @@ def _contract_group_native(clouds, moll, n_neighbors, max_iter, termination_rati
     cols = int(np.ceil(np.sqrt(S)))
     offs = np.array([[(j % cols) * pitch, (j // cols) * pitch, 0.0] for j in range(S)])
     offs -= np.array([0.5 * (p.max(0) + p.min(0)) for p in pts])
-    bounds = [oriented_bounds(p) for p in pts]
+    bounds = [oriented_bounds(p, device=device) for p in pts]
     lo = np.array([b[0] + o for b, o in zip(bounds, offs)])
     hi = np.array([b[1] + o for b, o in zip(bounds, offs)])
     cur = np.concatenate([p + o for p, o in zip(pts, offs)])
@@ -333,7 +356,7 @@ def _contract_group(clouds, moll, n_neighbors, max_iter, termination_ratio, cont
     cols = int(np.ceil(np.sqrt(S)))
     offs = np.array([[(j % cols) * pitch, (j // cols) * pitch, 0.0] for j in range(S)])
     offs -= np.array([0.5 * (p.max(0) + p.min(0)) for p in pts])
-    bounds = [oriented_bounds(p) for p in pts]                          # :240-241, per cloud
+    bounds = [oriented_bounds(p, device=device) for p in pts]           # :240-241, per cloud
     lo = np.concatenate([np.tile(b[0] + o, (n, 1)) for b, o, n in zip(bounds, offs, sizes)])
     hi = np.concatenate([np.tile(b[1] + o, (n, 1)) for b, o, n in zip(bounds, offs, sizes)])
     cur = np.concatenate([p + o for p, o in zip(pts, offs)])

@@ -442,6 +442,27 @@ def pc_laplacian(points, k: int = 30, moll: float = 1e-5, device: int = 0, seg_s
     return (indptr, indices, data), mass
 
 
+def extreme_points(points, dirs, device: int = 0) -> np.ndarray:
+    """Index of the point with the largest ``x . d`` for every row ``d`` of ``dirs`` [D,3]."""
+    pts = _points(points)
+    d = np.ascontiguousarray(np.asarray(dirs, dtype=np.float64).reshape(-1, 3))
+    idx = np.empty(len(d), dtype=np.int64)
+    check(_lib.load().pyqsm_extreme_points(_p(pts), pts.shape[0], _p(d), len(d), _p(idx), int(device)))
+    return idx
+
+
+def outside_halfspaces(points, equations, margin: float, device: int = 0) -> np.ndarray:
+    """Ascending indices of the points that are NOT strictly inside the polytope
+    ``a . x + o <= 0`` (rows ``(a, o)`` of ``equations`` [F,4], F <= 256)."""
+    pts = _points(points)
+    eq = np.ascontiguousarray(np.asarray(equations, dtype=np.float64).reshape(-1, 4))
+    idx = np.empty(pts.shape[0], dtype=np.int64)
+    count = i64(0)
+    check(_lib.load().pyqsm_outside_halfspaces(_p(pts), pts.shape[0], _p(eq), len(eq), float(margin),
+                                               _p(idx), ctypes.byref(count), int(device)))
+    return idx[:count.value].copy()
+
+
 # ---------------------------------------------------------------- the whole contraction loop
 
 def extract_skeleton(points, lo, hi, k: int, moll: float, max_iter: int, termination_ratio: float,

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import oracle
-from pyqsm_amd import synth
+from pyqsm_amd import hip, synth
 from pyqsm_amd.geometry.point_cloud_processing import cluster_and_get_largest, cluster_plus
 from pyqsm_amd.math_utils import fit
 from pyqsm_amd.viz import ray_casting as rc
@@ -144,3 +144,33 @@ def test_flat_imports_run_on_the_gpu(gpu):
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env,
                        cwd="/tmp")
     assert r.returncode == 0 and r.stdout.strip() == "True", r.stderr
+
+
+def test_hull_filters_keep_every_hull_vertex_and_the_oriented_bounds(gpu):
+    """pyqsm_extreme_points / pyqsm_outside_halfspaces in front of Qhull (skeletonize.py:240-241,
+    the clamp box of the contraction loop): the points listed as "not strictly inside" contain every
+    vertex of the cloud's convex hull, so the hull, the PCA of its vertices and the bounds are THE
+    SAME arrays as without the filter — for a forest, a ball, and a flat (degenerate) cloud."""
+    from scipy.spatial import ConvexHull
+    from pyqsm_amd.geometry import skeletonize as sk
+    rng = np.random.default_rng(3)
+    ball = rng.normal(size=(60_000, 3))
+    ball *= (rng.uniform(0, 1, (60_000, 1)) ** (1 / 3)) / np.linalg.norm(ball, axis=1, keepdims=True)
+    for P in (synth.forest(120_000, seed=6).astype(np.float64), ball):
+        d = sk._HULL_DIRS
+        ext = hip.extreme_points(P, d, device=gpu)
+        proj = P @ d.T
+        assert np.array_equal(proj[ext, np.arange(len(d))], proj.max(axis=0))
+        want = ConvexHull(P).vertices
+        got = sk._hull_vertices(P, device=gpu)
+        assert np.array_equal(got, want)
+        inner = ConvexHull(P[np.unique(ext)])
+        cand = hip.outside_halfspaces(P, inner.equations, 1e-9 * np.abs(P).max(), device=gpu)
+        assert np.all(np.diff(cand) > 0) and np.isin(want, cand).all() and len(cand) < 0.3 * len(P)
+        lo0, hi0 = sk.oriented_bounds(P)
+        lo1, hi1 = sk.oriented_bounds(P, device=gpu)
+        assert np.array_equal(lo0, lo1) and np.array_equal(hi0, hi1)
+    flat = np.column_stack([rng.uniform(0, 1, (30_000, 2)), np.zeros(30_000)])
+    lo0, hi0 = sk.oriented_bounds(flat)
+    lo1, hi1 = sk.oriented_bounds(flat, device=gpu)
+    assert np.array_equal(lo0, lo1) and np.array_equal(hi0, hi1)
