@@ -68,6 +68,12 @@ int pyqsm_h2d(int device, void* dst_dev, const void* src_host, size_t bytes);
 int pyqsm_d2h(int device, void* dst_host, const void* src_dev, size_t bytes);
 /* Release memory returned through an `**` out-parameter of a host entry point. */
 void pyqsm_free(void* p);
+/* A host buffer from the same pool those out-parameters come from: page-locked when it is a
+ * megabyte or more (plain malloc otherwise or when page-locking fails), released with pyqsm_free.
+ * Results written into such a buffer leave the device at link speed and without blocking the
+ * caller's thread; into pageable memory every 24 MB of pyqsm_extract_skeleton's per-step shifts
+ * cost 12 ms of staging (0.26 s of a 2.8 s loop). NULL when out of memory. */
+void* pyqsm_host_alloc(size_t bytes);
 
 /* HIP-event timers around named kernel groups on the library stream.
  * Disabled by default (zero overhead); bench.py switches them on to measure

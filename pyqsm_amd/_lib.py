@@ -28,6 +28,7 @@ SIGNATURES = {
     "pyqsm_h2d": (ctypes.c_int, [ctypes.c_int, vp, vp, ctypes.c_size_t]),
     "pyqsm_d2h": (ctypes.c_int, [ctypes.c_int, vp, vp, ctypes.c_size_t]),
     "pyqsm_free": (None, [vp]),
+    "pyqsm_host_alloc": (vp, [ctypes.c_size_t]),
     "pyqsm_prof_enable": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     "pyqsm_prof_reset": (ctypes.c_int, [ctypes.c_int]),
     "pyqsm_prof_get": (ctypes.c_int, [ctypes.c_int, ctypes.c_char_p, ctypes.POINTER(dbl),

@@ -399,6 +399,8 @@ int pyqsm_d2h(int device, void* dst, const void* src, size_t bytes) {
 
 void pyqsm_free(void* p) { out_free(p); }
 
+void* pyqsm_host_alloc(size_t bytes) { return out_alloc(bytes); }
+
 int pyqsm_prof_enable(int device, int on) {
   Ctx* c = ctx_for(device);
   if (!c) return PYQSM_ENODEV;

@@ -9,6 +9,7 @@
 // clamp box (:291-296), the volume ratio and the termination (:279, :349, :353) stay per cloud.
 // The loop's quirks are kept: the positional weights are updated with the mass of the Laplacian
 // just USED, and the volume ratio compares that mass with the first one (it lags one step).
+#include <chrono>
 #include "sparse.hpp"
 
 #include <cmath>
@@ -52,15 +53,29 @@ __global__ __launch_bounds__(256) void k_seg_flags(int n, const int32_t* __restr
                                                    const double* __restrict__ cur,
                                                    int32_t* __restrict__ flags) {
   int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  int f = 0;
+  int f = 0, sg = -1;
+  if (i < n) {
+    sg = seg_of[i];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const double a = nw[3 * size_t(i) + k], b = cur[3 * size_t(i) + k];
-    if (!(a == b)) f |= 1;
-    if (a == a) f |= 2;
+    for (int k = 0; k < 3; ++k) {
+      const double a = nw[3 * size_t(i) + k], b = cur[3 * size_t(i) + k];
+      if (!(a == b)) f |= 1;
+      if (a == a) f |= 2;
+    }
   }
-  if (f) atomicOr(&flags[seg_of[i]], f);
+  // One atomic per WAVE at most, none once the bits are there: every point OR-ing its bits into
+  // its cloud's word was a million atomics on ONE address for a single cloud — served one at a
+  // time, 11 ms per contraction step, 0.23 s of a 2.8 s loop.
+  const unsigned long long live = __ballot(i < n);
+  if (live == 0ull) return;
+  const int lead = __ffsll(live) - 1;
+  const int s0 = __shfl(sg, lead, 64);
+  if (__ballot(i < n && sg != s0) == 0ull) {  // the usual wave: one cloud
+    const int wf = (__ballot(f & 1) != 0ull ? 1 : 0) | (__ballot(f & 2) != 0ull ? 2 : 0);
+    if ((threadIdx.x & 63) == lead && wf && (flags[s0] & wf) != wf) atomicOr(&flags[s0], wf);
+  } else if (f && (flags[sg] & f) != f) {
+    atomicOr(&flags[sg], f);
+  }
 }
 
 // :291-307 for the clouds still active: clamp into the cloud's box, shift = cur - new,
@@ -207,6 +222,16 @@ int pyqsm_extract_skeleton(const double* xyz, int64_t n, const int64_t* seg_star
   if (!c) return PYQSM_ENODEV;
   std::lock_guard<std::mutex> lk(c->mu);
   c->arena.reset();
+  // host-side wall clock of the loop's phases (PYQSM_LBC_TRACE)
+  const bool trace_t = getenv("PYQSM_LBC_TRACE") != nullptr;
+  double t_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // setup, build, solve, means, step, tail, flags, kstep, copy
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t_mark = now();
+  auto lap = [&](int k) {
+    const double t = now();
+    t_acc[k] += t - t_mark;
+    t_mark = t;
+  };
   const int N = int(n);
   const dim3 gn(ceil_div(n, 256)), blk(256);
   DevBlock mem;
@@ -276,9 +301,12 @@ int pyqsm_extract_skeleton(const double* xyz, int64_t n, const int64_t* seg_star
       pyqsm_mean_f64(h_vec.data() + seg_start[s], seg_start[s + 1] - seg_start[s], &out[size_t(s)]);
     return 0;
   };
+  lap(0);
   PQ_TRY(build());                                                                    // :253-255
+  lap(1);
   PQ_HIP(hipMemcpyAsync(m0, m_used, size_t(n) * 8, hipMemcpyDeviceToDevice, c->stream));  // M_list[0]
   PQ_TRY(seg_means(m0, mean0));
+  lap(3);
   for (int s = 0; s < S; ++s)
     wl_seg[size_t(s)] = contraction_factor * 1000.0 * std::sqrt(mean0[size_t(s)]);     // :265
   int step = 0;
@@ -301,6 +329,7 @@ int pyqsm_extract_skeleton(const double* xyz, int64_t n, const int64_t* seg_star
     int rc = lbc_solve_device(c, Lp, n, wl, true, wh, cur, rtol, solver_max_it, nw, &it, rs);
     if (rc != 0 && rc != PYQSM_ENOCONV) return rc;
     PQ_HIP(hipStreamSynchronize(c->stream));
+    lap(2);
     c->arena.rewind(base);
     if (solve_iters) solve_iters[step] = it;
     if (solve_resid) solve_resid[step] = std::max(rs[0], std::max(rs[1], rs[2]));
@@ -311,6 +340,7 @@ int pyqsm_extract_skeleton(const double* xyz, int64_t n, const int64_t* seg_star
     PQ_HIP(hipGetLastError());
     PQ_HIP(hipMemcpyAsync(h_flags.data(), d_flags, size_t(S) * 4, hipMemcpyDeviceToHost, c->stream));
     PQ_HIP(hipStreamSynchronize(c->stream));
+    lap(6);
     for (int s = 0; s < S; ++s)
       if (active[size_t(s)] && (!(h_flags[size_t(s)] & 1) || !(h_flags[size_t(s)] & 2))) active[size_t(s)] = 0;
     ++step;
@@ -323,13 +353,17 @@ int pyqsm_extract_skeleton(const double* xyz, int64_t n, const int64_t* seg_star
     // ---- clamp, shift, accumulate (:291-307) -----------------------------------------
     PQ_HIP(hipMemcpyAsync(d_active, active.data(), size_t(S) * 4, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_step, gn, blk, 0, c->stream, N, seg_of, d_active, d_lo, d_hi, nw, cur, total, shift);
+    lap(7);
     if (steps)
       PQ_HIP(hipMemcpyAsync(steps + size_t(step - 1) * size_t(n) * 3, shift, size_t(n) * 24,
                             hipMemcpyDeviceToHost, c->stream));
+    lap(8);
     // ---- weights (:329-335) with the mass of the Laplacian just used ---------------------
     hipLaunchKernelGGL(k_wh_update, gn, blk, 0, c->stream, N, seg_of, d_active, m0, m_used, max_attraction, wh);
     PQ_HIP(hipGetLastError());
+    lap(4);
     PQ_TRY(seg_means(m_used, mean_used));                                              // M_list[-1] of :337
+    lap(3);
     for (int s = 0; s < S; ++s)
       if (active[size_t(s)]) {
         double w = wl_seg[size_t(s)] * contraction_factor;
@@ -340,15 +374,21 @@ int pyqsm_extract_skeleton(const double* xyz, int64_t n, const int64_t* seg_star
         ++n_steps[s];
       }
     PQ_TRY(build());                                                                  // :341-343
+    lap(1);
     for (int s = 0; s < S; ++s)
       if (active[size_t(s)]) {
         vr[size_t(s)] = mean_used[size_t(s)] / mean0[size_t(s)];                       // :349 (lags a step)
         if (iteration[size_t(s)] >= max_iter) active[size_t(s)] = 0;                   // :353-360
       }
   }
+  lap(4);
   PQ_HIP(hipMemcpyAsync(out_pts, cur, size_t(n) * 24, hipMemcpyDeviceToHost, c->stream));
   PQ_HIP(hipMemcpyAsync(total_shift, total, size_t(n) * 24, hipMemcpyDeviceToHost, c->stream));
   PQ_HIP(hipStreamSynchronize(c->stream));
+  lap(5);
+  if (trace_t)
+    fprintf(stderr, "extract_skeleton host clock: setup %.3f build %.3f solve %.3f means %.3f step %.3f tail %.3f s (flags %.3f kstep %.3f copy %.3f)\n",
+            t_acc[0], t_acc[1], t_acc[2], t_acc[3], t_acc[4], t_acc[5], t_acc[6], t_acc[7], t_acc[8]);
   return 0;
 }
 

@@ -415,6 +415,22 @@ def _adopt(lib, ptr, ctype, count: int, dtype):
     return np.frombuffer(buf, dtype=dtype, count=count)
 
 
+def host_empty(shape, dtype=np.float64) -> np.ndarray:
+    """``np.empty`` in the library's pool of page-locked host buffers (``pyqsm_host_alloc``): what
+    the device writes into it arrives at link speed and without blocking the calling thread. The
+    buffer goes back to the pool when the array and every view of it are gone."""
+    shape = tuple(int(q) for q in np.atleast_1d(shape))
+    dt = np.dtype(dtype)
+    count = int(np.prod(shape)) if len(shape) else 1
+    lib = _lib.load()
+    ptr = lib.pyqsm_host_alloc(max(count * dt.itemsize, 1))
+    if not ptr:
+        raise MemoryError("pyqsm_host_alloc failed")
+    buf = (ctypes.c_uint8 * max(count * dt.itemsize, 1)).from_address(ptr)
+    weakref.finalize(buf, lib.pyqsm_free, ctypes.c_void_p(ptr))
+    return np.frombuffer(buf, dtype=dt, count=count).reshape(shape)
+
+
 def pc_laplacian(points, k: int = 30, moll: float = 1e-5, device: int = 0, seg_start=None):
     """(indptr, indices, data) CSR triple and lumped mass [n]. ``seg_start`` (int64 [S+1], from 0
     to n): the points are S clouds stacked into one array and the mollification length is taken
@@ -481,9 +497,10 @@ def extract_skeleton(points, lo, hi, k: int, moll: float, max_iter: int, termina
     lo = np.ascontiguousarray(np.asarray(lo, dtype=np.float64).reshape(S, 3))
     hi = np.ascontiguousarray(np.asarray(hi, dtype=np.float64).reshape(S, 3))
     T = max(int(max_iter), 1)
-    out = np.empty_like(pts)
-    total = np.empty_like(pts)
-    steps = np.empty((T, n, 3)) if keep_steps else None     # rows < n_solves are written by the library
+    # page-locked results: the per-step shifts leave the device while the next step runs
+    out = host_empty(pts.shape)
+    total = host_empty(pts.shape)
+    steps = host_empty((T, n, 3)) if keep_steps else None   # rows < n_solves are written by the library
     n_steps = np.zeros(S, dtype=np.int32)
     iters = np.zeros(T, dtype=np.int32)
     resid = np.zeros(T)
