@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 def test_native_loop_equals_python_loop(gpu, n, c):
     P = synth.forest(n, seed=n)
     kw = dict(max_iter=8, termination_ratio=0.0, contraction_factor=c, attraction_factor=3)
-    g1, t1, s1 = sk.extract_skeleton(P, **kw)
+    g1, t1, s1 = sk.extract_skeleton(P, engine="python", **kw)
     g2, t2, s2 = sk.extract_skeleton(P, engine="native", **kw)
     assert len(s1) == len(s2) == 8 and len(g2.solve_log) == 8 and all(q["ok"] for q in g2.solve_log)
     for step, (a, b) in enumerate(zip(s1, s2)):
@@ -39,7 +39,7 @@ def test_native_loop_bookkeeping(gpu):
     P = synth.forest(8000, seed=5)
     for kw in (dict(max_iter=3, termination_ratio=0.0), dict(max_iter=6, termination_ratio=0.5),
                dict(max_iter=6, termination_ratio=0.9), dict(max_iter=0, termination_ratio=0.0)):
-        a = sk.extract_skeleton(P, contraction_factor=3, attraction_factor=3, **kw)
+        a = sk.extract_skeleton(P, contraction_factor=3, attraction_factor=3, engine="python", **kw)
         b = sk.extract_skeleton(P, contraction_factor=3, attraction_factor=3, engine="native", **kw)
         assert len(a[2]) == len(b[2]) == len(b[0].solve_log), kw
         assert np.array_equal(a[0].points, b[0].points), kw
