@@ -803,60 +803,84 @@ __device__ __forceinline__ bool ent_less(const Entry& a, const Entry& b) {
   return a.col < b.col || (a.col == b.col && a.key < b.key);
 }
 
-// Rank sort of one row by the wave with PER entries per lane (rows of up to 64 * PER
-// entries). (col, key) is compared as ONE 64-bit integer; equal pairs (both ends of a loop
-// edge of the flipped cover) keep their input order, so ranks stay a permutation.
+// Bitonic sort of one row by the wave, PER entries per lane (element e = lane + 64 t sits in lane
+// e % 64, slot e / 64; rows of up to 64 * PER entries, PER a power of two). (col, key) is compared
+// as ONE 64-bit integer. log2(N) (log2(N) + 1) / 2 compare-exchange stages — 28 for 128 entries —
+// of a lane shuffle and a select per entry, where the rank sort this replaces compared every
+// entry with every other one (1800 instructions for a 100-entry row, 4.6 ms per million rows;
+// now ~600). Not stable: the only equal (col, key) pairs are the two ends of a loop edge of the
+// flipped cover, which carry the same weight and are dropped from the row anyway.
 template <int PER>
 __device__ __forceinline__ void sort_row_wave(int i, int b, int m, int lane, Entry* __restrict__ ent,
                                               int32_t* __restrict__ nnz_row) {
+  constexpr int N = 64 * PER;
   unsigned long long ck[PER];
   double val[PER];
-  int rank[PER];
-  bool first[PER];
 #pragma unroll
   for (int t = 0; t < PER; ++t) {
     const int idx = lane + 64 * t;
-    ck[t] = ~0ull;
+    ck[t] = ~0ull;  // padding sorts to the end
     val[t] = 0.0;
-    rank[t] = 0;
-    first[t] = true;
     if (idx < m) {
       const Entry x = ent[b + idx];
       ck[t] = ((unsigned long long)(unsigned)x.col << 32) | (unsigned)x.key;
       val[t] = x.val;
     }
   }
+  for (int k = 2; k <= N; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      if (j >= 64) {  // partner in the same lane, another slot
+        const int dj = j >> 6;
 #pragma unroll
-  for (int cj = 0; cj < PER; ++cj) {
-    const int cnt = min(64, m - 64 * cj);  // <= 0 for chunks beyond the row
-    for (int l = 0; l < cnt; ++l) {
-      const unsigned lo = __builtin_amdgcn_readlane(unsigned(ck[cj]), l);
-      const unsigned hi = __builtin_amdgcn_readlane(unsigned(ck[cj] >> 32), l);
-      const unsigned long long o = ((unsigned long long)hi << 32) | lo;
-      const int src = 64 * cj + l;
+        for (int t = 0; t < PER; ++t) {
+          if ((t & dj) != 0) continue;
+          const int t2 = t | dj;
+          if (t2 >= PER) continue;
+          const bool asc = ((lane + 64 * t) & k) == 0;
+          const bool sw = asc ? ck[t] > ck[t2] : ck[t] < ck[t2];
+          const unsigned long long a = ck[t], c2 = ck[t2];
+          const double va = val[t], vc = val[t2];
+          ck[t] = sw ? c2 : a;
+          ck[t2] = sw ? a : c2;
+          val[t] = sw ? vc : va;
+          val[t2] = sw ? va : vc;
+        }
+      } else {  // partner in lane ^ j, same slot
+        const bool lower = (lane & j) == 0;
 #pragma unroll
-      for (int t = 0; t < PER; ++t) {
-        const bool less = o < ck[t] || (o == ck[t] && src < lane + 64 * t);
-        rank[t] += less ? 1 : 0;
-        if (less && hi == unsigned(ck[t] >> 32)) first[t] = false;
+        for (int t = 0; t < PER; ++t) {
+          const unsigned long long ok = __shfl_xor(ck[t], j, 64);
+          const double ov = __shfl_xor(val[t], j, 64);
+          const bool asc = ((lane + 64 * t) & k) == 0;
+          const bool keep_min = asc == lower;
+          const bool take = keep_min ? ok < ck[t] : ok > ck[t];
+          ck[t] = take ? ok : ck[t];
+          val[t] = take ? ov : val[t];
+        }
       }
     }
   }
   int distinct = 0;
 #pragma unroll
   for (int t = 0; t < PER; ++t) {
-    const bool valid = lane + 64 * t < m;
+    const int e = lane + 64 * t;
+    const bool valid = e < m;
     const int col = int(unsigned(ck[t] >> 32));
-    if (valid) ent[b + rank[t]] = Entry{col, int(unsigned(ck[t])), val[t]};
-    distinct += __popcll(__ballot(valid && first[t] && col != i));
+    // the entry before this one in sorted order: lane - 1, or lane 63 of the slot below
+    unsigned long long prev = __shfl_up(ck[t], 1, 64);
+    unsigned long long carry = 0ull;
+    if (t > 0) carry = __shfl(ck[t > 0 ? t - 1 : 0], 63, 64);
+    if (lane == 0) prev = carry;
+    const bool first = e == 0 || int(unsigned(prev >> 32)) != col;
+    if (valid) ent[b + e] = Entry{col, int(unsigned(ck[t])), val[t]};
+    distinct += __popcll(__ballot(valid && first && col != i));
   }
   if (lane == 0) nnz_row[i] = distinct + 1;  // + diagonal (loop edges i-i carry no weight)
 }
 
 // Sort the contributions of every row by (col, key) and count its distinct columns:
-// one wave per row, rank sort in registers (lane l holds entries l, l+64, ...; every
-// entry is broadcast once and compared by all lanes), so a 70-entry row costs ~70
-// broadcasts instead of ~1200 dependent global-memory moves of a per-lane insertion sort.
+// one wave per row, sorted in registers (sort_row_wave) instead of ~1200 dependent
+// global-memory moves of a per-lane insertion sort.
 static constexpr int kSortPer = 8;  // rows up to 64 * kSortPer entries take the wave path
 
 __global__ __launch_bounds__(256) void k_sort_rows(int n, const int32_t* __restrict__ row_start,
@@ -884,9 +908,10 @@ __global__ __launch_bounds__(256) void k_sort_rows(int n, const int32_t* __restr
     }
     return;
   }
-  // the usual row has 60-160 entries: no per-slot guards for it
-  if (m <= 128) sort_row_wave<2>(i, b, m, lane, ent, nnz_row);
-  else if (m <= 192) sort_row_wave<3>(i, b, m, lane, ent, nnz_row);
+  // the usual row has 60-160 entries
+  if (m <= 64) sort_row_wave<1>(i, b, m, lane, ent, nnz_row);
+  else if (m <= 128) sort_row_wave<2>(i, b, m, lane, ent, nnz_row);
+  else if (m <= 256) sort_row_wave<4>(i, b, m, lane, ent, nnz_row);
   else sort_row_wave<kSortPer>(i, b, m, lane, ent, nnz_row);
 }
 
