@@ -8,13 +8,15 @@
 // edge is tuned so that an occupied cell holds about k/3 points. One lane per
 // query walks Chebyshev shells of cells around its own cell (each shell row is
 // one contiguous run of the sorted arrays) and keeps the best k candidates sorted in
-// registers (k <= 32, k_knn_reg) or in a per-lane LDS column (element j of lane t at
-// [j*T + t]: conflict-free, k_knn). A
+// registers (k <= 32, k_knn_reg: by the distance alone in the first pass, ties detected and
+// searched again exactly — see the kernel) or in a per-lane LDS column (element j of lane t
+// at [j*T + t]: conflict-free, k_knn). A
 // query is final once its k-th distance is no larger than the radius the
 // visited cube is known to cover. The few queries that are not final after
-// kMaxRing shells (isolated outliers) are retried, one wave per query, on 4x coarser
-// grids derived from the fine one (grid.hip: coarsen_grid) until the shells cover the
-// whole grid.
+// kMaxRing shells (isolated outliers) are retried, one wave per query, on a 4x coarser
+// grid (binned from the points when the fine grid is large, else derived from it:
+// grid.hip: coarsen_grid) with up to kWideRing shells, and on coarser ones still until the
+// shells cover the whole grid.
 //
 // (Measured alternative for level 0, MI355X, 1 M points, k = 20: a wave-tiled search like
 // dbscan.hip's k_core_tiled — 64 consecutive queries, candidates broadcast from LDS, the K

@@ -9,14 +9,16 @@
 // point-cloud Laplacian is), so L' x is computed as L x.
 //
 // Uniform W_L = c I (what extract_skeleton always passes): flexible CG on A preconditioned
-// by B^-2, B = c L + W_H, each B-solve a CG preconditioned by one aggregation-multigrid
-// cycle (amg.hip), on spatially sorted unknowns — see lbc_solve_core / lbc_solve_device
-// below and DESIGN.md section 6. Per-point W_L: Jacobi-preconditioned CG on A.
+// by B^-2, B = c L + W_H — with Riccati-corrected weights while W_H is rough, in two phases
+// (k_riccati_f) — each B-solve a CG preconditioned by one aggregation-multigrid cycle
+// (amg.hip), on spatially sorted unknowns — see lbc_solve_core / lbc_solve_device below and
+// DESIGN.md section 6. Per-point W_L: Jacobi-preconditioned CG on A.
 //
 // HBM traffic of one sparse pass (fp64, CSR with 32-bit indices): 12*nnz + 52*n bytes
 // (SURVEY.md §8 d-roofline); the scalars of the inner CGs (alpha, beta, dot products) stay
-// on the device, iterations are replayed as hipGraphs, and the host looks at a residual
-// only between replays.
+// on the device as per-block partial sums that are added up in a fixed order (sparse.hpp: no
+// floating-point atomics, the same bits on every run), and the host looks at a residual only
+// between bursts of iterations.
 #include "grid.hpp"
 #include "sparse.hpp"
 
