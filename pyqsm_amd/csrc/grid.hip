@@ -98,13 +98,14 @@ struct GridParams {
 };
 
 __device__ __forceinline__ int cell_index(const GridParams& g, double x, double y, double z) {
-  // interior cells are 1 .. n-2; clamp guards the max-boundary point
-  int cx = int(floor((x - g.minx) * g.inv_cell)) + 1;
-  int cy = int(floor((y - g.miny) * g.inv_cell)) + 1;
-  int cz = int(floor((z - g.minz) * g.inv_cell)) + 1;
-  cx = cx < 1 ? 1 : (cx > g.nx - 2 ? g.nx - 2 : cx);
-  cy = cy < 1 ? 1 : (cy > g.ny - 2 ? g.ny - 2 : cy);
-  cz = cz < 1 ? 1 : (cz > g.nz - 2 ? g.nz - 2 : cz);
+  // interior cells are 1 .. n-2; the clamp guards the max-boundary point and puts points outside
+  // the grid's box into its outermost cells — clamped in double, so that a point a light year
+  // away does not overflow the int
+  const double fx = floor((x - g.minx) * g.inv_cell), fy = floor((y - g.miny) * g.inv_cell),
+               fz = floor((z - g.minz) * g.inv_cell);
+  const int cx = int(fmin(fmax(fx, 0.0), double(g.nx - 3))) + 1;
+  const int cy = int(fmin(fmax(fy, 0.0), double(g.ny - 3))) + 1;
+  const int cz = int(fmin(fmax(fz, 0.0), double(g.nz - 3))) + 1;
   return (cz * g.ny + cy) * g.nx + cx;
 }
 

@@ -93,3 +93,18 @@ def test_quantised_coordinates_have_ties_at_the_kth_place(gpu, k):
     print(f"k={k}: {tied:.1%} of the queries have equal distances among their neighbours")
     assert tied > 0.01
     assert np.array_equal(d2, d20) and np.array_equal(idx, idx0)
+
+
+def test_many_far_outliers_stay_exact(gpu):
+    """5 % of the points uniform in a box fifty times the cloud's size (the dense grid cannot have
+    the wanted cell edge, several retry levels run): indices and distances equal the oracle's,
+    for the outliers' own queries too."""
+    rng = np.random.default_rng(17)
+    P = synth.forest(40_000, seed=21)
+    ext = P.max(0) - P.min(0)
+    far = rng.uniform(P.min(0) - 25 * ext, P.max(0) + 25 * ext, (2000, 3))
+    X = np.concatenate([P, far])[rng.permutation(42_000)].astype(np.float32).astype(np.float64)
+    for k in (8, 20):
+        idx, d2 = hip.knn(X, k, True, device=gpu)
+        idx0, d20 = oracle.knn(X, k, True)
+        assert np.array_equal(d2, d20) and np.array_equal(idx, idx0)
