@@ -30,6 +30,7 @@ static constexpr int kInnerMaxIt = 200000;
 static constexpr int kOuterMaxIt = 600;
 static constexpr int kOuterStall = 12;
 static constexpr int kAmgMaxIt = 400;   // multigrid-preconditioned CG iterations per B-solve
+static constexpr int kF32MaxIt = 96;    // ... per fp32 B-solve: one that needs more has lost its digits (fp64 then)
 static constexpr int kRiccatiMaxIt = 8;            // Newton steps on the preconditioner's weights
 static constexpr double kRiccatiTol = 2e-3;        // |F| / |w^2| at which they are good enough (1e-2: the
                                                    // hardest contraction takes twice the outer steps)
@@ -928,6 +929,13 @@ static int amg_pcg_f32(Ctx* c, int N, const WorkF& w, AmgHierarchy* H, const flo
         return fail(PYQSM_ENOCONV, "multigrid CG (fp32) broke down after %d iterations", it);
       }
     }
+    // CG on an SPD system does not leave the residual ten times above the right-hand side for
+    // long: this one is diverging (see `diverged` in lbc_solve_core), no point in going to max_it
+    if (!done && it >= 16 && std::max(resid[0], std::max(resid[1], resid[2])) > 10.0) {
+      *iters = it;
+      return fail(PYQSM_ENOCONV, "multigrid CG (fp32) is diverging after %d iterations, residual %.3e", it,
+                  std::max(resid[0], std::max(resid[1], resid[2])));
+    }
   }
   PQ_HIP(hipGetLastError());
   *iters = it;
@@ -1171,29 +1179,66 @@ static int lbc_solve_core(Ctx* c, const DevCsr& L, int64_t n, const double* wl, 
   }
   // max_it caps the total number of inner (sparse-pass) iterations
   auto budget = [&]() { return std::max<int32_t>(1, std::min<int32_t>(kInnerMaxIt, max_it - total_inner)); };
+  // B-solves that break down: the fp32 multigrid CG loses its digits on the collapsed clouds of
+  // late contractions — cot weights of degenerate triangles put c L_ii at 1e12 where W_H is 1e3,
+  // below fp32's resolution of a row, and B^-1 r (the right-hand side of the second solve) is
+  // dominated by smooth modes whose residual fp32 cannot evaluate. Seen: one solve of a perturbed
+  // 20-contraction run spent 11 000 iterations feeding garbage to the outer iteration; a system
+  // with 30x the usual W_L took 1 753 iterations where the fp64 operator takes 376. An fp32 solve
+  // that diverges (amg_pcg_f32 returns after 16 iterations) or needs more than kF32MaxIt
+  // iterations is therefore repeated one rung down — fp64 operator with the same cycle — and
+  // the solve stays there; an fp64 solve that DIVERGES goes on to Jacobi-PCG.
+  // (CG's residual is not monotone: a solve cut short by the caller's max_it after a few
+  // iterations may stand above 1 without diverging, and an exhausted budget is not spent again.)
+  auto diverged = [&](int rc, int32_t its, const double rs[3]) {
+    if (rc == 0 || total_inner >= max_it) return false;
+    const double w = std::max(rs[0], std::max(rs[1], rs[2]));
+    return !std::isfinite(w) || (its >= 16 && w > 1.0);
+  };
+  int rung = 0;  // 0: fp32 multigrid CG, 1: fp64 operator, 2: Jacobi-PCG
   auto precond = [&](const double* rhs, double* out) -> int {  // out = B^-1 B^-1 rhs
     int32_t it1 = 0, it2 = 0;
     double rs[3];
-    if (amg && use_f32) {
+    if (amg && use_f32 && rung == 0) {
       hipLaunchKernelGGL(k_cvt_d2f, grid, block, 0, c->stream, N, rhs, f_rhs);
-      int rc = amg_pcg_f32(c, N, wf, amg, f_rhs, f_y, kInnerRtol, std::min(budget(), kAmgMaxIt), &cache, &it1,
+      int rc = amg_pcg_f32(c, N, wf, amg, f_rhs, f_y, kInnerRtol, std::min(budget(), kF32MaxIt), &cache, &it1,
                            rs);
       if (rc != 0 && rc != PYQSM_ENOCONV) return rc;
       total_inner += it1;
-      rc = amg_pcg_f32(c, N, wf, amg, f_y, f_out, kInnerRtol, std::min(budget(), kAmgMaxIt), &cache, &it2, rs);
-      if (rc != 0 && rc != PYQSM_ENOCONV) return rc;
-      total_inner += it2;
-      hipLaunchKernelGGL(k_cvt_f2d, grid, block, 0, c->stream, N, f_out, out);
-      return 0;
+      bool bad = rc != 0 && total_inner < max_it;  // fp32: stalling counts as well
+      if (!bad) {
+        rc = amg_pcg_f32(c, N, wf, amg, f_y, f_out, kInnerRtol, std::min(budget(), kF32MaxIt), &cache, &it2, rs);
+        if (rc != 0 && rc != PYQSM_ENOCONV) return rc;
+        total_inner += it2;
+        bad = rc != 0 && total_inner < max_it;
+      }
+      if (!bad) {
+        hipLaunchKernelGGL(k_cvt_f2d, grid, block, 0, c->stream, N, f_out, out);
+        return 0;
+      }
+      rung = 1;
+      if (trace)
+        fprintf(stderr, "  fp32 B-solve gave up after %d + %d iterations (%.3e %.3e %.3e): fp64 operator from here\n",
+                it1, it2, rs[0], rs[1], rs[2]);
+      it1 = it2 = 0;
     }
-    if (amg) {
+    if (amg && rung <= 1) {
       int rc = amg_pcg(c, SB, wb, amg, rhs, y, kInnerRtol, std::min(budget(), kAmgMaxIt), &cache, &it1, rs);
       if (rc != 0 && rc != PYQSM_ENOCONV) return rc;
       total_inner += it1;
-      rc = amg_pcg(c, SB, wb, amg, y, out, kInnerRtol, std::min(budget(), kAmgMaxIt), &cache, &it2, rs);
-      if (rc != 0 && rc != PYQSM_ENOCONV) return rc;
-      total_inner += it2;
-      return 0;
+      bool bad = diverged(rc, it1, rs);
+      if (!bad) {
+        rc = amg_pcg(c, SB, wb, amg, y, out, kInnerRtol, std::min(budget(), kAmgMaxIt), &cache, &it2, rs);
+        if (rc != 0 && rc != PYQSM_ENOCONV) return rc;
+        total_inner += it2;
+        bad = diverged(rc, it2, rs);
+      }
+      if (!bad) return 0;
+      rung = 2;
+      if (trace)
+        fprintf(stderr, "  multigrid B-solve diverged after %d + %d iterations (%.3e %.3e %.3e): Jacobi-PCG from here\n",
+                it1, it2, rs[0], rs[1], rs[2]);
+      it1 = it2 = 0;
     }
     int rc = jacobi_pcg(c, SB, wb, rhs, y, true, kInnerRtol, budget(), "lbc_inner_iter", &cache, &it1,
                         rs);

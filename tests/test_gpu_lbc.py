@@ -5,6 +5,7 @@ import os
 
 import numpy as np
 import pytest
+import scipy.sparse as sp
 from scipy.sparse import csr_matrix
 
 import oracle
@@ -168,3 +169,42 @@ def test_riccati_weighted_preconditioner_same_solution_fewer_iterations(gpu, mon
     print(f"rough W_H: plain {it0} iterations, Riccati {it1}; difference {np.abs(x0 - x1).max() / scale:.1e}")
     assert np.abs(x0 - x1).max() <= 1e-6 * scale
     assert it1 < it0
+
+
+def test_diverging_fp32_inner_solve_falls_back_to_the_fp64_operator(gpu, monkeypatch, capfd):
+    """On a collapsed cloud with a very large W_L the fp32 multigrid-CG solves of the
+    preconditioner B^-1 B^-1 diverge (c L_ii ~ 1e9 next to W_H = 0.1 is beyond what fp32 rows
+    resolve; DESIGN.md section 6, "fp32 breakdown"). lbc.hip's ladder notices within 16
+    iterations and repeats the application with the fp64 operator, so the solve still ends with
+    ok = True and agrees with the solve that never used fp32 (PYQSM_LBC_F32=0). The true residual
+    of A = W_L^2 L^T L + W_H^2 (pyQSM/geometry/skeletonize.py:134-137) cannot be the check here:
+    with entries of 1e24 its evaluation in fp64 carries more rounding than |b|."""
+    from pyqsm_amd import synth
+    from pyqsm_amd.geometry import skeletonize as sk
+    P = synth.forest(30_000, seed=4)
+    systems = []
+    inner = sk.least_squares_sparse
+
+    def capture(pts, L, laplacian_weighting, positional_weighting, **kw):
+        systems.append((L.copy(), laplacian_weighting.copy(), positional_weighting.copy(), pts.copy()))
+        return inner(pts=pts, L=L, laplacian_weighting=laplacian_weighting,
+                     positional_weighting=positional_weighting, **kw)
+
+    monkeypatch.setattr(sk, "least_squares_sparse", capture)
+    sk.extract_skeleton(P, max_iter=16, termination_ratio=0.0, contraction_factor=7, attraction_factor=3)
+    monkeypatch.undo()
+    L, wl, wh, pts = systems[-1]
+    wl = wl * 1000.0
+    monkeypatch.setenv("PYQSM_LBC_TRACE", "1")
+    capfd.readouterr()
+    x, iters, resid, ok = hip.lbc_solve(L, wl, wh, pts, rtol=1e-8, max_it=20_000, device=gpu)
+    err = capfd.readouterr().err
+    assert "fp64 operator from here" in err, "the fp32 inner solve was expected to break down on this system"
+    monkeypatch.delenv("PYQSM_LBC_TRACE")
+    monkeypatch.setenv("PYQSM_LBC_F32", "0")
+    x64, iters64, _, ok64 = hip.lbc_solve(L, wl, wh, pts, rtol=1e-8, max_it=20_000, device=gpu)
+    assert ok and ok64 and np.isfinite(x).all()
+    diff = np.abs(x - x64).max() / np.abs(x64).max()
+    print(f"ladder {iters} iterations, fp64 only {iters64}; difference {diff:.1e}")
+    assert diff <= 1e-6
+    assert iters <= iters64 + 200           # the failed fp32 attempt costs tens of iterations, not thousands
