@@ -597,6 +597,14 @@ static int amg_fixed_iterations() {
 
 static constexpr int kAmgFirstBurst = 8;  // a 1e-2 solve takes 10-14 iterations: no look before 8
 static constexpr int kAmgBurst = 2;       // then a residual check every 2
+static int amg_first_burst() {
+  static const int v = [] {
+    const char* e = getenv("PYQSM_AMG_FIRST_BURST");
+    const int b = e ? atoi(e) : kAmgFirstBurst;
+    return b >= 2 && b <= 64 ? (b & ~1) : kAmgFirstBurst;
+  }();
+  return v;
+}
 
 // CG on B y = rhs preconditioned by one multigrid V-cycle (amg.hip). Same device-side
 // scalar protocol as jacobi_pcg: an iteration is the sparse pass, the update, the cycle
@@ -654,7 +662,7 @@ static int amg_pcg(Ctx* c, const System& S, const Work& w, AmgHierarchy* H, cons
   int it = 0;
   bool done = false;
   while (!done && it < max_it) {
-    int len = it == 0 ? kAmgFirstBurst : kAmgBurst;
+    int len = it == 0 ? amg_first_burst() : kAmgBurst;
     if (len > max_it - it) len = std::max(2, (max_it - it + 1) & ~1);  // even: bursts start at parity 0
     {
       ProfScope ps(c, "lbc_amg_iter", len);
@@ -901,7 +909,7 @@ static int amg_pcg_f32(Ctx* c, int N, const WorkF& w, AmgHierarchy* H, const flo
     return 0;
   }
   while (!done && it < max_it) {
-    int len = it == 0 ? kAmgFirstBurst : kAmgBurst;
+    int len = it == 0 ? amg_first_burst() : kAmgBurst;
     if (len > max_it - it) len = std::max(2, (max_it - it + 1) & ~1);
     {
       ProfScope ps(c, "lbc_amg_iter", len);

@@ -177,7 +177,7 @@ def test_diverging_fp32_inner_solve_falls_back_to_the_fp64_operator(gpu, monkeyp
     resolve; DESIGN.md section 6, "fp32 breakdown"). lbc.hip's ladder notices within 16
     iterations and repeats the application with the fp64 operator, so the solve still ends with
     ok = True and agrees with the solve that never used fp32 (PYQSM_LBC_F32=0). The true residual
-    of A = W_L^2 L^T L + W_H^2 (pyQSM/geometry/skeletonize.py:134-137) cannot be the check here:
+    of A = W_L L^T L W_L + W_H^2 (pyQSM/geometry/skeletonize.py:134-137) cannot be the check here:
     with entries of 1e24 its evaluation in fp64 carries more rounding than |b|."""
     from pyqsm_amd import synth
     from pyqsm_amd.geometry import skeletonize as sk
