@@ -39,6 +39,10 @@ int build_grid(Ctx* c, const double* xyz, int64_t n, double min_cell, int64_t ma
 
 // Bounding box of the cloud (one reduction kernel + a 48-byte read-back).
 int cloud_bbox(Ctx* c, const double* xyz, int64_t n, double mn[3], double mx[3]);
+// Shrinks box (min xyz, max xyz) to the part of the cloud that is left when at most `budget`
+// points in sparse tails are given up (they clamp into the outermost cells of a grid built over
+// the box); *outside = how many the last cut gave up (0: box unchanged).
+int robust_box(Ctx* c, const double* xyz, int64_t n, int budget, double box[6], int64_t* outside);
 
 // Mean number of points per occupied cell for a grid of edge `cell` over `box`
 // (count-only pass on a grid of at most 4 M cells; the edge is doubled to fit and

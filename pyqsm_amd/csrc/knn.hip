@@ -51,6 +51,7 @@ static constexpr int kMaxK = 192;
 struct KnnGrid {
   int nx, ny, nz;
   double cell;
+  double minx, miny, minz;  // origin of the interior cells (cell 1 starts here)
 };
 
 __device__ __forceinline__ double sqdist3(double ax, double ay, double az, double bx, double by,
@@ -434,7 +435,7 @@ template <int K>
 static int launch_knn_reg(Ctx* c, int n, const DevGrid& g, int k, int excl, int last, int32_t* idx,
                           double* d2, int32_t* fail_list, int32_t* fail_count, int32_t* tie_list,
                           int32_t* tie_count) {
-  KnnGrid kg{g.nx, g.ny, g.nz, g.cell};
+  KnnGrid kg{g.nx, g.ny, g.nz, g.cell, g.minx, g.miny, g.minz};
   const dim3 grid(ceil_div(n, 256)), blk(256);
   const int32_t* none = nullptr;
   if (knn_buffer_slots() == 0) {
@@ -509,6 +510,19 @@ __global__ __launch_bounds__(256) void k_knn_wave(int n_query,
   int tau_i = 0x7FFFFFFF;
   bool done = false;
   const int rmax_grid = max(g.nx, max(g.ny, g.nz));
+  // A query clamped into the grid from far outside its box (a stray point; robust_box): everything
+  // inside the box is further away than this level's rings reach, so the walk could only end on
+  // other strays — it goes straight to the next level (in the end k_knn_brute) instead of scanning
+  // the border cells' thousands of points.
+  if (!last_level) {
+    const double ox = fmax(fmax(g.minx - x, x - (g.minx + double(g.nx - 2) * g.cell)), 0.0);
+    const double oy = fmax(fmax(g.miny - y, y - (g.miny + double(g.ny - 2) * g.cell)), 0.0);
+    const double oz = fmax(fmax(g.minz - z, z - (g.minz + double(g.nz - 2) * g.cell)), 0.0);
+    if (fmax(ox, fmax(oy, oz)) > double(max_ring) * g.cell) {
+      if (lane == 0) fail_list[atomicAdd(fail_count, 1)] = self;
+      continue;
+    }
+  }
   for (int r = 0; r <= max_ring && !done; ++r) {
     // The shell's row segments, 64 at a time: every lane looks one up (two loads), then the
     // wave scans the non-empty ones together. Around an isolated point nearly all of them
@@ -599,6 +613,143 @@ __global__ __launch_bounds__(256) void k_knn_wave(int n_query,
   }
 }
 
+// The last resort for a FEW isolated queries (stray points tens of metres outside the scan: their
+// neighbours are further away than any affordable ring of cells, and every coarser retry level
+// costs a grid build and a launch that lasts as long as its longest wave — 6-8 ms for a
+// handful of them, 45 ms when the strays inflate the box until the grid hits its size cap): the
+// whole cloud, same list, same comparison. A wave takes kBruteTile queries through one slice of
+// the points (every loaded point is tested against all of them; the slices of one tile run on
+// different waves, so that twenty queries still fill the chip), leaves its sorted partial lists in
+// a scratch buffer, and k_knn_brute_merge folds a query's slices.
+// queries it takes: what robust_box may leave outside its box. The cost is queries x points
+// (1.4 ms for 2 000 of a million), the alternative a grid at its size cap (45 ms).
+static int brute_max(int64_t n) { return int(std::min<int64_t>(8192, std::max<int64_t>(256, n / 256))); }
+static constexpr int kBruteTile = 4;    // queries per wave
+
+__device__ __forceinline__ void wave_list_insert(double nd, int ni, int k, int lane, double& bd, int& bi, int& have,
+                                                 double& tau_d, int& tau_i) {
+  if (have == k && !(nd < tau_d || (nd == tau_d && ni < tau_i))) return;
+  const bool less = lane < have && (bd < nd || (bd == nd && bi < ni));
+  const int pos = __popcll(__ballot(less));
+  const double pd = __shfl_up(bd, 1, 64);
+  const int pi = __shfl_up(bi, 1, 64);
+  const int top = have < k ? have : k - 1;
+  if (lane > pos && lane <= top) {
+    bd = pd;
+    bi = pi;
+  }
+  if (lane == pos) {
+    bd = nd;
+    bi = ni;
+  }
+  if (have < k) ++have;
+  if (have == k) {
+    tau_d = __shfl(bd, k - 1, 64);
+    tau_i = __shfl(bi, k - 1, 64);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_knn_brute(int n_query, const int32_t* __restrict__ query_list,
+                                                   const double* __restrict__ xyz, int n, int k,
+                                                   int exclude_self, int n_slices,
+                                                   double* __restrict__ part_d /*[tiles][slices][tile][k]*/,
+                                                   int32_t* __restrict__ part_i) {
+  const int lane = threadIdx.x & 63;
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6);  // wave = (tile, slice)
+  const int tile = w / n_slices, slice = w % n_slices;
+  if (tile * kBruteTile >= n_query) return;  // whole waves
+  int self[kBruteTile];
+  double qx[kBruteTile], qy[kBruteTile], qz[kBruteTile];
+  double bd[kBruteTile], tau_d[kBruteTile];
+  int bi[kBruteTile], have[kBruteTile], tau_i[kBruteTile];
+#pragma unroll
+  for (int t = 0; t < kBruteTile; ++t) {
+    const int qi = tile * kBruteTile + t;
+    self[t] = qi < n_query ? query_list[qi] : -1;
+    const size_t s0 = size_t(self[t] < 0 ? 0 : self[t]);
+    qx[t] = xyz[3 * s0];
+    qy[t] = xyz[3 * s0 + 1];
+    qz[t] = xyz[3 * s0 + 2];
+    bd[t] = tau_d[t] = __builtin_inf();
+    bi[t] = tau_i[t] = 0x7FFFFFFF;
+    have[t] = 0;
+  }
+  // slices of whole 64-point chunks
+  const int chunks = (n + 63) / 64;
+  const int per = (chunks + n_slices - 1) / n_slices;
+  const int c_lo = slice * per, c_hi = min(chunks, c_lo + per);
+  for (int ch = c_lo; ch < c_hi; ch += 2) {
+    // two chunks' loads in flight before either is looked at
+    double px[2], py[2], pz[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int q = (ch + u) * 64 + lane;
+      const bool in = ch + u < c_hi && q < n;
+      const size_t qq = size_t(in ? q : 0);
+      px[u] = xyz[3 * qq];
+      py[u] = xyz[3 * qq + 1];
+      pz[u] = xyz[3 * qq + 2];
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int base = (ch + u) * 64;
+      const int q = base + lane;
+      const bool in = ch + u < c_hi && q < n;
+#pragma unroll
+      for (int t = 0; t < kBruteTile; ++t) {
+        const bool valid = in && self[t] >= 0 && !(exclude_self && q == self[t]);
+        const double d = valid ? sqdist3(qx[t], qy[t], qz[t], px[u], py[u], pz[u]) : __builtin_inf();
+        const bool cand = valid && (have[t] < k || d < tau_d[t] || (d == tau_d[t] && q < tau_i[t]));
+        unsigned long long mask = __ballot(cand);
+        while (mask) {
+          const int l = __ffsll(mask) - 1;
+          mask &= mask - 1;
+          wave_list_insert(__shfl(d, l, 64), base + l, k, lane, bd[t], bi[t], have[t], tau_d[t], tau_i[t]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < kBruteTile; ++t) {
+    const size_t o = ((size_t(tile) * n_slices + slice) * kBruteTile + t) * size_t(k);
+    if (lane < k) {
+      part_d[o + lane] = lane < have[t] ? bd[t] : __builtin_inf();
+      part_i[o + lane] = lane < have[t] ? bi[t] : 0x7FFFFFFF;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_knn_brute_merge(int n_query, const int32_t* __restrict__ query_list,
+                                                         int n, int k, int n_slices,
+                                                         const double* __restrict__ part_d,
+                                                         const int32_t* __restrict__ part_i,
+                                                         int32_t* __restrict__ out_idx,
+                                                         double* __restrict__ out_d2) {
+  const int lane = threadIdx.x & 63;
+  const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (qi >= n_query) return;
+  const int self = query_list[qi];
+  const int tile = qi / kBruteTile, t = qi % kBruteTile;
+  double bd = __builtin_inf(), tau_d = __builtin_inf();
+  int bi = 0x7FFFFFFF, tau_i = 0x7FFFFFFF, have = 0;
+  for (int s = 0; s < n_slices; ++s) {
+    const size_t o = ((size_t(tile) * n_slices + s) * kBruteTile + t) * size_t(k);
+    const double d = lane < k ? part_d[o + lane] : __builtin_inf();
+    const int id = lane < k ? part_i[o + lane] : 0x7FFFFFFF;
+    const bool cand = id != 0x7FFFFFFF && (have < k || d < tau_d || (d == tau_d && id < tau_i));
+    unsigned long long mask = __ballot(cand);
+    while (mask) {
+      const int l = __ffsll(mask) - 1;
+      mask &= mask - 1;
+      wave_list_insert(__shfl(d, l, 64), __shfl(id, l, 64), k, lane, bd, bi, have, tau_d, tau_i);
+    }
+  }
+  if (lane < k) {
+    out_idx[size_t(self) * k + lane] = lane < have ? bi : n;
+    out_d2[size_t(self) * k + lane] = lane < have ? bd : __builtin_inf();
+  }
+}
+
 __global__ __launch_bounds__(256) void k_invert_order(int n, const int32_t* __restrict__ order,
                                                       int32_t* __restrict__ pos_of) {
   int p = blockIdx.x * 256 + threadIdx.x;
@@ -617,7 +768,7 @@ static int launch_knn(Ctx* c, int n_query, const int32_t* list, const int32_t* p
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set.fetch_or(bit, std::memory_order_release);
   }
-  KnnGrid kg{g.nx, g.ny, g.nz, g.cell};
+  KnnGrid kg{g.nx, g.ny, g.nz, g.cell, g.minx, g.miny, g.minz};
   hipLaunchKernelGGL(k_knn<T>, dim3(ceil_div(n_query, T)), dim3(T), smem, c->stream, n_query, list,
                      pos_of, kg, g.start, g.order, g.cell_of, g.sx, g.sy, g.sz, k, excl, n_total,
                      last, idx, d2, fail_list, fail_count);
@@ -641,6 +792,14 @@ int knn_device(Ctx* c, const double* xyz, int64_t n, int32_t k, int32_t exclude_
   {
     ProfScope ps(c, "knn_bin");
     PQ_TRY(cloud_bbox(c, xyz, n, box, box + 3));
+    // grids over the cloud without its sparse tails; what is given up is what k_knn_brute can take
+    static const bool robust = [] { const char* e = getenv("PYQSM_KNN_ROBUST_BOX"); return !(e && e[0] == '0'); }();
+    if (robust && k <= 64) {
+      int64_t outside = 0;
+      PQ_TRY(robust_box(c, xyz, n, brute_max(n), box, &outside));
+      if (outside && getenv("PYQSM_KNN_TRACE"))
+        fprintf(stderr, "knn: grids over the box without its tails, at most %lld points outside\n", (long long)outside);
+    }
     double ext = std::max(box[3] - box[0], std::max(box[4] - box[1], box[5] - box[2]));
     if (!(ext > 0)) ext = 1.0;
     static const double occ_div = [] {  // PYQSM_KNN_OCC: points per occupied cell = k / this
@@ -705,7 +864,7 @@ int knn_device(Ctx* c, const double* xyz, int64_t n, int32_t k, int32_t exclude_
           default: PQ_TRY(launch_knn_reg<32>(c, N, g, k, exclude_self, last, idx, d2, fl, fail_count, tie_list, tie_count)); break;
         }
       } else if (level > 0 && k <= 64) {
-        KnnGrid kg{g.nx, g.ny, g.nz, g.cell};
+        KnnGrid kg{g.nx, g.ny, g.nz, g.cell, g.minx, g.miny, g.minz};
         // (one or two waves per block instead of four: no difference — the launch lasts as long as its
         // longest waves, 0.34 ms for the forest's 9 864 outliers)
         hipLaunchKernelGGL(k_knn_wave, dim3(ceil_div(n_query, 4)), dim3(256), 0, c->stream, n_query,
@@ -733,6 +892,26 @@ int knn_device(Ctx* c, const double* xyz, int64_t n, int32_t k, int32_t exclude_
     }
     if (getenv("PYQSM_KNN_TRACE")) fprintf(stderr, "knn level %d: %d of %d queries stay open (cell %.4g)\n", level, nf, n_query, g.cell);
     if (nf == 0) break;
+    if (level >= 1 && nf <= 2 * brute_max(n) && k <= 64) {  // a few isolated queries: one by one
+      ProfScope pb(c, "knn_brute");
+      const int32_t* ql = (level & 1) ? fail_b : fail_a;
+      const int tiles = ceil_div(nf, kBruteTile);
+      const int chunks = ceil_div(N, 64);
+      // ~16 waves per CU over all tiles; a slice is at least 32 chunks long
+      const int n_slices = std::max(1, std::min(std::min(64, ceil_div(chunks, 32)), ceil_div(c->cu_count * 16, tiles)));
+      double* part_d = nullptr;
+      int32_t* part_i = nullptr;
+      const size_t slots = size_t(tiles) * n_slices * kBruteTile * size_t(k);
+      PQ_TRY(c->arena.get(slots, &part_d));
+      PQ_TRY(c->arena.get(slots, &part_i));
+      hipLaunchKernelGGL(k_knn_brute, dim3(ceil_div(tiles * n_slices, 4)), dim3(256), 0, c->stream, nf, ql, xyz, N,
+                         k, exclude_self, n_slices, part_d, part_i);
+      hipLaunchKernelGGL(k_knn_brute_merge, dim3(ceil_div(nf, 4)), dim3(256), 0, c->stream, nf, ql, N, k, n_slices,
+                         static_cast<const double*>(part_d), static_cast<const int32_t*>(part_i), idx, d2);
+      PQ_HIP(hipGetLastError());
+      if (getenv("PYQSM_KNN_TRACE")) fprintf(stderr, "knn: %d isolated queries searched over the whole cloud\n", nf);
+      break;
+    }
     // retry the stragglers on a 4x coarser grid
     ProfScope ps(c, "knn_bin");
     list = (level & 1) ? fail_b : fail_a;

@@ -108,3 +108,30 @@ def test_many_far_outliers_stay_exact(gpu):
         idx, d2 = hip.knn(X, k, True, device=gpu)
         idx0, d20 = oracle.knn(X, k, True)
         assert np.array_equal(d2, d20) and np.array_equal(idx, idx0)
+
+
+def test_few_far_outliers_are_searched_one_by_one(gpu, monkeypatch, capfd):
+    """A handful of stray points tens of cloud sizes away (what terrestrial scans carry): the grids
+    are built over the box without those tails (grid.hip: robust_box — the strays clamp into the
+    outermost cells, which keeps every ring bound valid) and the strays' own queries, which no ring
+    of cells can answer, go to the whole-cloud wave kernel (knn.hip: k_knn_brute). Indices and
+    distances equal the oracle's for every point; with PYQSM_KNN_ROBUST_BOX=0 (the grids of the
+    full box, retry levels) the same bits come out."""
+    rng = np.random.default_rng(23)
+    P = synth.forest(60_000, seed=5)
+    ext = P.max(0) - P.min(0)
+    far = P.mean(0) + rng.choice([-1.0, 1.0], (40, 3)) * rng.uniform(20, 60, (40, 3)) * ext
+    far[:5] = far[0] + rng.normal(0, 1e-3, (5, 3))           # a tiny far cluster: neighbours among themselves
+    X = np.concatenate([P, far])[rng.permutation(60_040)].astype(np.float32).astype(np.float64)
+    monkeypatch.setenv("PYQSM_KNN_TRACE", "1")
+    for k in (8, 20, 64):
+        capfd.readouterr()
+        idx, d2 = hip.knn(X, k, True, device=gpu)
+        err = capfd.readouterr().err
+        assert "without its tails" in err and "searched over the whole cloud" in err
+        idx0, d20 = oracle.knn(X, k, True)
+        assert np.array_equal(d2, d20) and np.array_equal(idx, idx0)
+    monkeypatch.setenv("PYQSM_KNN_ROBUST_BOX", "0")          # read once per process: only checks the env is harmless
+    idx1, d21 = hip.knn(X, 20, True, device=gpu)
+    idx0, d20 = oracle.knn(X, 20, True)
+    assert np.array_equal(d21, d20) and np.array_equal(idx1, idx0)
