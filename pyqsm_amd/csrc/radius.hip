@@ -51,6 +51,14 @@ struct RGrid {
   int nx, ny, nz;
 };
 
+__device__ __forceinline__ void clamped_cell(const RGrid& g, double x, double y, double z, int* cx, int* cy,
+                                             int* cz) {
+  const double fx = floor((x - g.minx) * g.inv), fy = floor((y - g.miny) * g.inv), fz = floor((z - g.minz) * g.inv);
+  *cx = int(fmin(fmax(fx, 0.0), double(g.nx - 3))) + 1;
+  *cy = int(fmin(fmax(fy, 0.0), double(g.ny - 3))) + 1;
+  *cz = int(fmin(fmax(fz, 0.0), double(g.nz - 3))) + 1;
+}
+
 // MODE 0: count of source points with d2 < r2.  MODE 1: count with d2 <= tau.
 // MODE 2: mark every source point with d2 < bound (bound = r2, or tau plus ties).
 template <int MODE>
@@ -60,11 +68,12 @@ __device__ __forceinline__ int walk(const RGrid& g, const int32_t* __restrict__ 
                                     const double* __restrict__ sz, double x, double y, double z,
                                     double r2, double tau, int budget, uint8_t* __restrict__ mark,
                                     int32_t* __restrict__ lab_out = nullptr, int lab = 0) {
-  int cx = int(floor((x - g.minx) * g.inv)) + 1;
-  int cy = int(floor((y - g.miny) * g.inv)) + 1;
-  int cz = int(floor((z - g.minz) * g.inv)) + 1;
-  // queries may lie outside the source grid: more than one cell away nothing is in range
-  if (cx < 0 || cy < 0 || cz < 0 || cx > g.nx - 1 || cy > g.ny - 1 || cz > g.nz - 1) return 0;
+  // The query's cell, clamped into the grid the way the sources were binned (grid.hip: cell_index):
+  // the grid may cover less than the cloud (source_grid below), and a clamp moves no two points
+  // further apart, so whatever is within the radius of a query outside still sits in the 27 cells
+  // around its clamped cell; the distance test is on the true coordinates.
+  int cx, cy, cz;
+  clamped_cell(g, x, y, z, &cx, &cy, &cz);
   int cnt = 0;
   for (int dz = -1; dz <= 1; ++dz) {
     const int zz = cz + dz;
@@ -147,10 +156,8 @@ struct RowRuns {
 
 __device__ __forceinline__ bool query_runs(const RGrid& g, const int32_t* __restrict__ start,
                                            double x, double y, double z, RowRuns* rr) {
-  const int cx = int(floor((x - g.minx) * g.inv)) + 1;
-  const int cy = int(floor((y - g.miny) * g.inv)) + 1;
-  const int cz = int(floor((z - g.minz) * g.inv)) + 1;
-  if (cx < 0 || cy < 0 || cz < 0 || cx > g.nx - 1 || cy > g.ny - 1 || cz > g.nz - 1) return false;
+  int cx, cy, cz;
+  clamped_cell(g, x, y, z, &cx, &cy, &cz);
   int w = 0;
   for (int dz = -1; dz <= 1; ++dz)
     for (int dy = -1; dy <= 1; ++dy, ++w) {
@@ -272,6 +279,17 @@ __global__ __launch_bounds__(128) void k_radius_knn(int m, const double* __restr
   }
 }
 
+// The grid of the source points: cells of the radius, over the cloud without its sparse tails (a few
+// stray returns far outside would otherwise inflate the box until the dense grid cannot have cells
+// of the radius any more — every doubling of the edge is 8x the points per cell).
+static int source_grid(Ctx* c, const double* d_src, int64_t n, double radius, DevGrid* g) {
+  double box[6];
+  PQ_TRY(cloud_bbox(c, d_src, n, box, box + 3));
+  int64_t outside = 0;
+  PQ_TRY(robust_box(c, d_src, n, int(std::min<int64_t>(8192, std::max<int64_t>(256, n / 256))), box, &outside));
+  return build_grid(c, d_src, n, radius * (1.0 + 1.0 / 1048576.0), int64_t(1) << 28, g, box);
+}
+
 }  // namespace pyqsm
 
 using namespace pyqsm;
@@ -345,7 +363,7 @@ int pyqsm_radius_mark(const double* src, int64_t n, const double* qry, int64_t m
   PQ_HIP(hipMemcpyAsync(d_qry, qry, size_t(m) * 24, hipMemcpyHostToDevice, c->stream));
   PQ_HIP(hipMemsetAsync(d_mark, 0, size_t(n), c->stream));
   DevGrid g;
-  PQ_TRY(build_grid(c, d_src, n, radius * (1.0 + 1.0 / 1048576.0), int64_t(1) << 28, &g));
+  PQ_TRY(source_grid(c, d_src, n, radius, &g));
   RGrid rg{g.minx, g.miny, g.minz, g.inv_cell, g.nx, g.ny, g.nz};
   {
     ProfScope ps(c, "radius_mark");
@@ -390,7 +408,7 @@ int pyqsm_radius_knn(const double* src, int64_t n, const double* qry, int64_t m,
   PQ_HIP(hipMemcpyAsync(d_src, src, size_t(n) * 24, hipMemcpyHostToDevice, c->stream));
   PQ_HIP(hipMemcpyAsync(d_qry, qry, size_t(m) * 24, hipMemcpyHostToDevice, c->stream));
   DevGrid g;
-  PQ_TRY(build_grid(c, d_src, n, radius * (1.0 + 1.0 / 1048576.0), int64_t(1) << 28, &g));
+  PQ_TRY(source_grid(c, d_src, n, radius, &g));
   RGrid rg{g.minx, g.miny, g.minz, g.inv_cell, g.nx, g.ny, g.nz};
   {
     ProfScope ps(c, "radius_knn");
@@ -438,7 +456,7 @@ int pyqsm_radius_label(const double* src, int64_t n, const double* qry, int64_t 
   PQ_HIP(hipMemcpyAsync(d_qlab, qry_label, size_t(m) * 4, hipMemcpyHostToDevice, c->stream));
   PQ_HIP(hipMemsetAsync(d_lab, 0x7F, size_t(n) * 4, c->stream));  // 0x7F7F7F7F > any label
   DevGrid g;
-  PQ_TRY(build_grid(c, d_src, n, radius * (1.0 + 1.0 / 1048576.0), int64_t(1) << 28, &g));
+  PQ_TRY(source_grid(c, d_src, n, radius, &g));
   RGrid rg{g.minx, g.miny, g.minz, g.inv_cell, g.nx, g.ny, g.nz};
   {
     ProfScope ps(c, "radius_label");

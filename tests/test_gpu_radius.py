@@ -91,3 +91,32 @@ def test_radius_knn_tables_match_ckdtree(gpu, k, radius):
     assert (np.isinf(d[:, 0])).sum() > 100             # some queries find nothing
     if k <= 40:
         assert full > 100                              # the k cap is exercised
+
+
+def test_stray_source_points_far_outside_keep_radius_queries_exact(gpu):
+    """A few source points tens of cloud sizes away: the source grid is built over the cloud without
+    those tails (radius.hip: source_grid; they clamp into its outermost cells) and queries — inside,
+    next to a stray, and far from everything — still get cKDTree's answers: the union-of-balls mask
+    with its per-query counts, and the padded distance tables."""
+    rng = np.random.default_rng(9)
+    P = synth.forest(40_000, seed=4)
+    ext = P.max(0) - P.min(0)
+    far = P.mean(0) + rng.choice([-1.0, 1.0], (30, 3)) * rng.uniform(15, 40, (30, 3)) * ext
+    far[:6] = far[0] + rng.normal(0, 0.02, (6, 3))                       # a far clump: neighbours among themselves
+    src = np.concatenate([P, far])[rng.permutation(40_030)].astype(np.float32).astype(np.float64)
+    qry = np.concatenate([P[::61] + [0.01, -0.02, 0.005], far + rng.normal(0, 0.01, far.shape),
+                          far[0] + [[5.0, 0, 0]], [[1e4, -1e4, 1e4]]]).astype(np.float32).astype(np.float64)
+    for dist, k in ((0.1, 500), (0.3, 7)):
+        mask, counts = hip.radius_mark(src, qry, dist, k=k, device=gpu)
+        want_idx, want_counts = _kdtree_union(src, qry, dist, k)
+        assert np.array_equal(counts, want_counts)
+        assert np.array_equal(np.flatnonzero(mask), want_idx)
+    assert want_counts[-32:-2].max() >= 5                                # the far clump was found
+    d0, i0 = cKDTree(src).query(qry, k=8, distance_upper_bound=0.1)
+    d, i = get_neighbors_kdtree(src, query_pts=qry, dist=0.1, k=8, return_pcd=False, device=gpu)
+    assert np.array_equal(d, d0.reshape(len(qry), 8))
+    distinct = np.isfinite(d) & (np.r_["1", d[:, 1:] != d[:, :-1], np.ones((len(d), 1), bool)])
+    distinct[:, 1:] &= d[:, 1:] != d[:, :-1]
+    assert np.array_equal(i[distinct], i0.reshape(len(qry), 8)[distinct])
+    got = hip.ball_query(src, far[0], 0.2, device=gpu)
+    assert np.array_equal(got, np.sort(cKDTree(src).query_ball_point(far[0], 0.2)))
