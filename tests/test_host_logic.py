@@ -321,3 +321,17 @@ def test_draw_samples_rows_are_distinct_uniform_and_seeded():
     assert np.array_equal(draw_samples(50, 10, seed=5, method="stdlib"), want)
     with pytest.raises(ValueError):
         draw_samples(2, 4)
+
+
+def test_unique_rows_mm_equals_numpy_row_unique():
+    """skeleton_to_QSM's per-cylinder ``np.unique(points.round(3), axis=0)`` (skeletonize.py:409 of the
+    reference: ``to_points(...).round(3).unique()``) on integer millimetre keys: the same rows in the
+    same order, also for negative coordinates, for duplicates and past the 21-bit range (fallback)."""
+    from pyqsm_amd.geometry.skeletonize import _unique_rows_mm
+    rng = np.random.default_rng(0)
+    for scale, shift in ((1.0, 0.0), (0.01, -5.0), (30.0, 100.0), (5000.0, 0.0)):
+        r = (rng.normal(0, scale, (3000, 3)) + shift).round(3)
+        r[::7] = r[3]                                            # duplicates
+        got = _unique_rows_mm(r)
+        want = np.unique(r, axis=0)
+        assert got.shape == want.shape and np.array_equal(got, want), scale
