@@ -227,6 +227,20 @@ int pyqsm_ransac_models(const double* pts, int64_t n, const int64_t* triples, in
                         double* models, int32_t device);
 int pyqsm_ransac_count(const double* pts, int64_t n, const double* models, int64_t H,
                        int32_t shape, double thresh, int32_t* counts, int32_t device);
+/*
+ * Many independent fits in one call — the z-slices of a stem, each fitted like
+ * pyQSM/math_utils/fit.py:277-283 fits one cluster (a call per slice is 0.6 ms of
+ * launches and round trips for 0.05 ms of work). S point sets stacked in pts
+ * (seg_start i64 [S+1], from 0 to n), H hypotheses per set: triples i64 [S,H,3]
+ * with indices LOCAL to the set (a set with fewer than three points gets rows of -1).
+ * Per set what pyqsm_ransac returns: centers f64 [S,3], axes f64 [S,3], radii f64 [S],
+ * best i64 [S] (-1: no hypothesis with an inlier), n_inliers i64 [S], and the inliers
+ * as ascending local indices, set after set, in inliers i64 [n] (capacity).
+ */
+int pyqsm_ransac_batch(const double* pts, int64_t n, const int64_t* seg_start, int64_t n_seg,
+                       const int64_t* triples, int64_t H, int32_t shape, double thresh,
+                       double* centers, double* axes, double* radii, int64_t* inliers,
+                       int64_t* n_inliers, int64_t* best, int32_t device);
 
 /* ---- Laplacian-contraction solve --------------------------------------- */
 /*

@@ -57,6 +57,7 @@ SIGNATURES = {
                                     ctypes.POINTER(i64), ctypes.POINTER(i64), i32]),
     "pyqsm_ransac_models": (ctypes.c_int, [vp, i64, vp, i64, vp, i32]),
     "pyqsm_ransac_count": (ctypes.c_int, [vp, i64, vp, i64, i32, dbl, vp, i32]),
+    "pyqsm_ransac_batch": (ctypes.c_int, [vp, i64, vp, i64, vp, i64, i32, dbl, vp, vp, vp, vp, vp, vp, i32]),
     "pyqsm_lbc_solve": (ctypes.c_int, [vp, vp, vp, i64, vp, vp, vp, dbl, i32, vp,
                                        ctypes.POINTER(i32), vp, i32]),
     "pyqsm_spmv3": (ctypes.c_int, [vp, vp, vp, i64, vp, vp, i32]),

@@ -264,6 +264,34 @@ def ransac(points, triples, shape: str = "circle", thresh: float = 0.2, device: 
     return center, axis, radius.value, inl[:n_in.value].copy(), int(best.value)
 
 
+def ransac_batch(points, seg_start, triples, shape: str = "circle", thresh: float = 0.2, device: int = 0):
+    """``pyqsm_ransac_batch``: S point sets stacked in ``points`` (``seg_start`` int64 [S+1]), H
+    hypotheses each (``triples`` int64 [S,H,3], indices local to the set). Returns ``(centers [S,3],
+    axes [S,3], radii [S], inliers list of S int64 arrays (ascending, local), best int64 [S])``."""
+    pts = _points(points)
+    ss = np.ascontiguousarray(seg_start, dtype=np.int64)
+    S = len(ss) - 1
+    tri = np.ascontiguousarray(np.asarray(triples), dtype=np.int64).reshape(S, -1, 3)
+    H = tri.shape[1]
+    sizes = np.diff(ss)
+    if H and S:
+        ok = (tri >= 0).all(axis=(1, 2)) | (sizes < 3)
+        if not ok.all() or (tri.max(axis=(1, 2)) >= np.maximum(sizes, 1))[sizes >= 3].any():
+            raise ValueError("sample index outside its point set")
+    centers = np.zeros((S, 3))
+    axes = np.zeros((S, 3))
+    radii = np.zeros(S)
+    inl = np.empty(max(pts.shape[0], 1), dtype=np.int64)
+    n_in = np.zeros(S, dtype=np.int64)
+    best = np.full(S, -1, dtype=np.int64)
+    check(_lib.load().pyqsm_ransac_batch(_p(pts), pts.shape[0], _p(ss), S, _p(tri), H, SHAPES[shape],
+                                         float(thresh), _p(centers), _p(axes), _p(radii), _p(inl), _p(n_in),
+                                         _p(best), int(device)))
+    ends = np.cumsum(n_in)
+    inliers = [inl[e - c:e].copy() for c, e in zip(n_in, ends)]
+    return centers, axes, radii, inliers, best
+
+
 def ransac_models(points, triples, device: int = 0):
     """f64 [H,8] = (cx,cy,cz, ax,ay,az, r, valid)."""
     pts = _points(points)

@@ -88,3 +88,50 @@ def test_degenerate_samples_and_empty(gpu):
     assert best == -1 and len(inl) == 0
     c, a, r, inl, best = hip.ransac(pts, np.zeros((0, 3), np.int64), "circle", 0.04, device=gpu)
     assert best == -1 and len(inl) == 0
+
+
+@pytest.mark.parametrize("shape", ["circle", "cylinder"])
+def test_batch_equals_one_call_per_set(gpu, shape):
+    """pyqsm_ransac_batch: stacked sets of very different sizes (one empty, one with two points, one
+    larger than a tile, one where no hypothesis has an inlier) give, set by set, the bits of
+    pyqsm_ransac: model, winning row, inlier indices. Then the same through
+    fit_shape_RANSAC_batch against fit_shape_RANSAC (fit.py:253-339), rejections included."""
+    from pyqsm_amd.math_utils import fit
+    rng = np.random.default_rng(8)
+    sets = []
+    for n, r in ((400, 0.3), (0, 0.0), (2, 0.0), (3000, 0.12), (57, 0.05), (1500, 0.6)):
+        a = rng.uniform(0, 2 * np.pi, n)
+        P = np.stack([r * np.cos(a) + rng.normal(0, 0.004, n) + 3.0, r * np.sin(a) + rng.normal(0, 0.004, n) - 1.0,
+                      rng.uniform(0.0, 0.5, n)], axis=1)
+        P[: n // 5] += rng.normal(0, 0.2, (n // 5, 3))                  # outliers
+        sets.append(P)
+    sets.append(np.arange(30.0).reshape(10, 3) * [1.0, 0.0, 0.0])          # collinear: no valid model
+    H = 300
+    seg = np.concatenate([[0], np.cumsum([len(p) for p in sets])])
+    tri = np.stack([fit.draw_samples(len(p), H, seed=3) if len(p) >= 3 else np.full((H, 3), -1) for p in sets])
+    flat = [p.copy() for p in sets]
+    if shape == "circle":
+        for p in flat:
+            p[:, 2] = 0.0
+    c, a, r, inl, best = hip.ransac_batch(np.concatenate(flat), seg, tri, shape, 0.03, device=gpu)
+    for q, p in enumerate(flat):
+        if len(p) < 3:
+            assert best[q] == -1 and len(inl[q]) == 0
+            continue
+        c1, a1, r1, inl1, b1 = hip.ransac(p, tri[q], shape, 0.03, device=gpu)
+        assert b1 == best[q]
+        assert np.array_equal(inl1, inl[q])
+        if b1 >= 0:
+            assert np.array_equal(c1, c[q]) and np.array_equal(a1, a[q]) and r1 == r[q]
+    assert best[-1] == -1 and best[0] >= 0 and best[3] >= 0
+    got = fit.fit_shape_RANSAC_batch([p.copy() for p in sets], threshold=0.03, max_radius=0.5, shape=shape,
+                                     samples=list(tri), device=gpu)
+    for q, p in enumerate(sets):
+        want = fit.fit_shape_RANSAC(pts=p.copy(), threshold=0.03, max_radius=0.5, shape=shape,
+                                    samples=tri[q], device=gpu)
+        if want[0] is None:
+            assert got[q][0] is None
+            continue
+        assert np.array_equal(want[2], got[q][2]) and want[3] == got[q][3] and np.array_equal(want[4], got[q][4])
+        assert np.array_equal(want[0].center, got[q][0].center) and want[0].height == got[q][0].height
+    assert got[5][0] is None                                               # radius 0.6 > max_radius
