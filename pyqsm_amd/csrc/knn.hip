@@ -793,7 +793,8 @@ int knn_device(Ctx* c, const double* xyz, int64_t n, int32_t k, int32_t exclude_
     ProfScope ps(c, "knn_bin");
     PQ_TRY(cloud_bbox(c, xyz, n, box, box + 3));
     // grids over the cloud without its sparse tails; what is given up is what k_knn_brute can take
-    static const bool robust = [] { const char* e = getenv("PYQSM_KNN_ROBUST_BOX"); return !(e && e[0] == '0'); }();
+    const char* rbe = getenv("PYQSM_KNN_ROBUST_BOX");  // "0": grids over the full box
+    const bool robust = !(rbe && rbe[0] == '0');
     if (robust && k <= 64) {
       int64_t outside = 0;
       PQ_TRY(robust_box(c, xyz, n, brute_max(n), box, &outside));

@@ -131,7 +131,9 @@ def test_few_far_outliers_are_searched_one_by_one(gpu, monkeypatch, capfd):
         assert "without its tails" in err and "searched over the whole cloud" in err
         idx0, d20 = oracle.knn(X, k, True)
         assert np.array_equal(d2, d20) and np.array_equal(idx, idx0)
-    monkeypatch.setenv("PYQSM_KNN_ROBUST_BOX", "0")          # read once per process: only checks the env is harmless
+    monkeypatch.setenv("PYQSM_KNN_ROBUST_BOX", "0")          # grids over the full box, retry levels
+    capfd.readouterr()
     idx1, d21 = hip.knn(X, 20, True, device=gpu)
+    assert "without its tails" not in capfd.readouterr().err
     idx0, d20 = oracle.knn(X, 20, True)
     assert np.array_equal(d21, d20) and np.array_equal(idx1, idx0)
