@@ -899,7 +899,7 @@ int knn_device(Ctx* c, const double* xyz, int64_t n, int32_t k, int32_t exclude_
       const int tiles = ceil_div(nf, kBruteTile);
       const int chunks = ceil_div(N, 64);
       // ~16 waves per CU over all tiles; a slice is at least 32 chunks long
-      const int n_slices = std::max(1, std::min(std::min(64, ceil_div(chunks, 32)), ceil_div(c->cu_count * 16, tiles)));
+      const int n_slices = std::max(1, std::min(std::min(256, ceil_div(chunks, 32)), ceil_div(c->cu_count * 16, tiles)));
       double* part_d = nullptr;
       int32_t* part_i = nullptr;
       const size_t slots = size_t(tiles) * n_slices * kBruteTile * size_t(k);
