@@ -452,6 +452,33 @@ def main():
                          "ms_per_fit": dt * 1e3, "value": H * nr / dt / 1e6,
                          "unit": "Mpoint-hypothesis tests/s", "inliers": int(len(res[3])),
                          "dtype": "f64"}
+        # config 5's shape: the ten 0.5 m z-slices of one tree, together (pyqsm_ransac_batch) and one by one
+        tree = synth.forest(50_000, seed=0)
+        slices = []
+        for z0 in np.arange(0.5, 5.5, 0.5):
+            sl = tree[(tree[:, 2] >= z0) & (tree[:, 2] < z0 + 0.5)].copy()
+            sl[:, 2] = 0.0
+            if len(sl) >= 50:
+                slices.append(sl)
+        if slices:
+            seg = np.concatenate([[0], np.cumsum([len(q) for q in slices])]).astype(np.int64)
+            tri = np.stack([np.stack([rng.choice(len(q), 3, replace=False) for _ in range(H)]) for q in slices])
+            stacked = np.concatenate(slices)
+            for _ in range(5):
+                batch = hip.ransac_batch(stacked, seg, tri, "circle", 0.04, dev)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                batch = hip.ransac_batch(stacked, seg, tri, "circle", 0.04, dev)
+            tb = (time.perf_counter() - t0) / reps
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                single = [hip.ransac(q, t, "circle", 0.04, dev) for q, t in zip(slices, tri)]
+            ts = (time.perf_counter() - t0) / reps
+            same = all(np.array_equal(a[3], b) and a[4] == c for a, b, c in zip(single, batch[3], batch[4]))
+            out["ransac"]["slices_of_a_tree"] = {
+                "sets": len(slices), "points": int(seg[-1]), "hypotheses_per_set": H,
+                "ms_one_batch_call": tb * 1e3, "ms_one_call_per_slice": ts * 1e3,
+                "same_inliers_and_winner": bool(same)}
         if rank == 0 and not args.no_cpu:
             import oracle
             hs = 100
