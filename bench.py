@@ -19,7 +19,9 @@ Secondary sections on the same JSON line:
   roofline    dominant kernel of the primary path, HIP-event timed live
   skeleton    the first --skel-iters Laplacian contractions of extract_skeleton on the
               same cloud with the time split Laplacian / solve (N = 1 only: replicas)
-  ransac      1000 circle hypotheses x 50 k points (fit_shape_RANSAC's inner loop)
+  ransac      1000 circle hypotheses x 50 k points (fit_shape_RANSAC's inner loop); the ten z-slices of
+              a tree in one pyqsm_ransac_batch call and one by one
+  fps         farthest-point sampling of 10 % of the cloud (what extract_topology does next)
   cpu_baseline  scikit-learn DBSCAN (the reference's own call, fit.py:223) on the
               host cores of this box, rank 0, N = 1 only
 """
@@ -215,6 +217,22 @@ def main():
                                            "neighbour class) + 12 B x k of result rows; the kernel is "
                                            "bound by its per-candidate register insertion (FP64 VALU "
                                            "issue), not by HBM"}}
+        if world == 1:
+            # the same cloud with twenty stray returns 3-10 cloud sizes away (what terrestrial scans carry):
+            # grids over the box without its tails + whole-cloud search of the strays
+            srng = np.random.default_rng(3)
+            stray = pts.copy()
+            ext_c = pts.max(0) - pts.min(0)
+            stray[srng.choice(n, 20, replace=False)] = (pts.mean(0) + srng.choice([-1.0, 1.0], (20, 3))
+                                                        * srng.uniform(3, 10, (20, 3)) * ext_c)
+            d_stray = hip.DeviceBuffer.from_array(stray, dev)
+            hip.knn_dev(d_stray.ptr, n, k, True, d_idx.ptr, d_d2.ptr, dev)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                hip.knn_dev(d_stray.ptr, n, k, True, d_idx.ptr, d_d2.ptr, dev)
+            out["knn"]["with_20_stray_points_ms"] = (time.perf_counter() - t0) / 3 * 1e3
+            d_stray.free()
+            hip.knn_dev(d_xyz.ptr, n, k, True, d_idx.ptr, d_d2.ptr, dev)   # the baseline below reads these
         if rank == 0 and world == 1 and not args.no_cpu:
             from scipy.spatial import cKDTree
             t0 = time.perf_counter()
@@ -492,6 +510,25 @@ def main():
                 "sample": f"first {hs} of the {H} hypotheses, NumPy restatement of pyransac3d's "
                           "Circle.fit loop (oracle.ransac_fit); same inliers as GPU: "
                           f"{bool(np.array_equal(np.asarray(ref[3]), sub[3]))}"}
+
+    # ------------------------------------------------------------- farthest-point sampling
+    if not args.no_skeleton and world == 1:
+        # extract_topology keeps 10 % of the contracted cloud (skeletonize.py:127-132): 1 M -> 100 k here,
+        # on the bench's own forest (the pruned rounds do not depend on the cloud being contracted)
+        s_fps = n // 10
+        hip.fps(pts, 2000, 0, dev)
+        t0 = time.perf_counter()
+        picked = hip.fps(pts, s_fps, 0, dev)
+        t_pruned = time.perf_counter() - t0
+        os.environ["PYQSM_FPS_PRUNE"] = "0"
+        t0 = time.perf_counter()
+        whole = hip.fps(pts, s_fps, 0, dev)
+        t_whole = time.perf_counter() - t0
+        del os.environ["PYQSM_FPS_PRUNE"]
+        out["fps"] = {"points": n, "samples": s_fps, "s_pruned_rounds": t_pruned, "s_whole_cloud_rounds": t_whole,
+                      "us_per_sample": t_pruned / s_fps * 1e6,
+                      "same_indices": bool(np.array_equal(picked, whole)), "dtype": "f64",
+                      "note": "host buffers in and out; whole-cloud rounds move 32 B per point and sample"}
 
     # ------------------------------------------------------------- CPU baseline (primary)
     if rank == 0 and world == 1 and not args.no_cpu:
