@@ -225,7 +225,7 @@ int probe_occupancy(Ctx* c, const double* xyz, int64_t n, const double box[6], d
 
 // ---- a box without the cloud's sparse tails --------------------------------------------
 // A scan with a few stray returns tens of metres outside would have its search grids sized for
-// mostly empty space (a million points at k = 20: 5.6 ms instead of 2.2). Binning CLAMPS into the
+// mostly empty space (a million points at k = 20: up to 50 ms instead of 2.3). Binning CLAMPS into the
 // outermost cells (cell_index), and a clamp moves no two points further apart, so a grid over a
 // smaller box stays exact for searches that bound distances from below by cell rings; what it
 // costs is that the clamped points themselves find their neighbours late. The box is therefore
