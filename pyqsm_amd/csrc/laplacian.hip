@@ -675,7 +675,7 @@ __global__ __launch_bounds__(256) void k_flip_apply(const int32_t* __restrict__ 
   // wave-uniform trip count: the appends below are wave-cooperative
   for (int base = blockIdx.x * 256; base < m; base += gridDim.x * 256) {
   const int i = base + threadIdx.x;
-  int push[5];
+  int push[4];
   int np = 0;
   bool flipped = false;
   if (i < m && is_cand[i]) {
@@ -746,7 +746,8 @@ __global__ __launch_bounds__(256) void k_flip_apply(const int32_t* __restrict__ 
       push[np++] = min(3 * f + 2, n_ka);
       push[np++] = min(3 * g + 0, n_bk);
       push[np++] = min(3 * g + 2, n_lb);
-      push[np++] = min(3 * f + 1, 3 * g + 1);
+      // (the flipped edge itself is Delaunay now, by more than the tolerance; it comes back on a
+      // list as an outer edge of whichever neighbouring flip next changes one of its faces)
     }
   }
   // stamp-deduplicated append
