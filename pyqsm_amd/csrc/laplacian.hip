@@ -955,6 +955,120 @@ __global__ __launch_bounds__(256) void k_rows(int n, const int32_t* __restrict__
   vals[diag_pos] = diag;
 }
 
+// The same, a wave per row (four rows per block): a thread per row walked ~100 sorted 16-byte entries
+// and as many random face areas one after the other (2.2-3.7 ms per million rows); here the lanes
+// load 64 entries at a time, equal columns are summed by a segmented scan over the lanes (in the
+// sorted order: a fixed summation tree, the same bits on every run), a column that continues
+// into the next chunk is carried, and the merged entries are written at the place their rank
+// among the row's distinct columns gives them, the diagonal slotted in before the first column
+// beyond it.
+__global__ __launch_bounds__(256) void k_rows_wave(int n, const int32_t* __restrict__ row_start,
+                                                   const Entry* __restrict__ ent,
+                                                   const double* __restrict__ tri_area,
+                                                   const int32_t* __restrict__ indptr,
+                                                   int32_t* __restrict__ indices,
+                                                   double* __restrict__ vals,
+                                                   double* __restrict__ mass) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;  // whole waves
+  const int b = row_start[i], e = row_start[i + 1];
+  // lumped mass: a third of the faces around the vertex (each face is listed twice)
+  double m = 0.0;
+  for (int a = b + lane; a < e; a += 64) m += tri_area[ent[a].key >> 2] * 0.5;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m += __shfl_xor(m, off, 64);
+  if (lane == 0) mass[i] = (m / 3.0) / 3.0;
+  const int w0 = indptr[i];
+  int written = 0;      // merged off-diagonals written so far
+  int below = 0;        // ... of them with a column below i
+  double diag = 0.0;    // minus their sum (accumulated in lane 0's copy; all lanes keep the same value)
+  bool have_carry = false;
+  int carry_col = 0;
+  double carry_sum = 0.0;
+  auto emit = [&](int col, double sum, int rank_in_batch) {  // one merged entry
+    const int pos = w0 + written + rank_in_batch + (col > i ? 1 : 0);
+    indices[pos] = col;
+    vals[pos] = sum;
+  };
+  for (int base = b; base < e; base += 64) {
+    const int a = base + lane;
+    const bool valid = a < e;
+    const Entry en = valid ? ent[a] : Entry{0x7FFFFFFF, 0, 0.0};
+    const int col = en.col;
+    const int prev_col = __shfl_up(col, 1, 64);
+    // a lane starts a run when its column differs from the lane before it (lane 0: from the carry)
+    const bool head = valid && (lane == 0 ? !(have_carry && col == carry_col) : col != prev_col);
+    const bool joins_carry = have_carry && __shfl(col, 0, 64) == carry_col;  // wave-uniform
+    // a carried column that does not continue here is complete: it goes out first
+    if (have_carry && !joins_carry) {
+      if (carry_col != i) {
+        if (lane == 0) emit(carry_col, carry_sum, 0);
+        written += 1;
+        below += carry_col < i ? 1 : 0;
+        diag -= carry_sum;
+      }
+      have_carry = false;
+    }
+    // Runs inside the chunk: lane 0 starts one in any case (a run that continues the carry takes
+    // the carried sum first). The lane that starts a run adds its entries one after the other, in
+    // the sorted (column, key) order — the order the thread-per-row kernel used, and the SAME order
+    // for L_ij and L_ji, which is what keeps L symmetric to the bit; a tree over the lanes would
+    // depend on where in the chunk a run happens to sit.
+    const bool starts = valid && (head || lane == 0);
+    const unsigned long long start_mask = __ballot(starts);
+    const int n_valid = __popcll(__ballot(valid));
+    const unsigned long long later = lane == 63 ? 0ull : (start_mask & ~((2ull << lane) - 1ull));
+    const int run_end = later ? __ffsll(later) - 1 : n_valid;  // one past my run's last lane
+    const int my_len = starts ? run_end - lane : 0;
+    int max_len = my_len;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) max_len = max(max_len, __shfl_xor(max_len, off, 64));
+    const double val = valid ? en.val : 0.0;
+    double sum = (lane == 0 && have_carry && joins_carry) ? carry_sum + val : val;
+    for (int t = 1; t < max_len; ++t) {
+      const double tv = __shfl_down(val, t, 64);
+      if (t < my_len) sum += tv;
+    }
+    const bool final_chunk = base + 64 >= e;
+    // the run at the end of a chunk that is not the row's last may go on: carried, not written
+    const bool pending = starts && run_end == n_valid && !final_chunk;
+    const bool out = starts && !pending && col != i;  // (col == i: a loop edge of the flipped cover, cancels in L)
+    const unsigned long long outs = __ballot(out);
+    if (out) emit(col, sum, __popcll(outs & ((1ull << lane) - 1ull)));
+    // bookkeeping, the same in every lane
+    const unsigned long long lows = __ballot(out && col < i);
+    double dsum = out ? sum : 0.0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) dsum += __shfl_xor(dsum, off, 64);
+    diag -= dsum;
+    written += __popcll(outs);
+    below += __popcll(lows);
+    const unsigned long long pend = __ballot(pending);
+    if (pend) {
+      const int src = __ffsll(pend) - 1;
+      have_carry = true;
+      carry_col = __shfl(col, src, 64);
+      carry_sum = __shfl(sum, src, 64);
+    } else {
+      have_carry = false;
+    }
+  }
+  if (have_carry) {  // (only when the row's length is a multiple of 64 ... and then the last run was final: not reached)
+    if (carry_col != i) {
+      if (lane == 0) emit(carry_col, carry_sum, 0);
+      written += 1;
+      below += carry_col < i ? 1 : 0;
+      diag -= carry_sum;
+    }
+  }
+  if (lane == 0) {
+    const int diag_pos = w0 + below;
+    indices[diag_pos] = i;
+    vals[diag_pos] = diag;
+  }
+}
+
 }  // namespace pyqsm
 
 using namespace pyqsm;
@@ -1152,8 +1266,13 @@ int laplacian_device(Ctx* c, const double* d_xyz, int64_t n, const int64_t* seg_
   double* d_vals;
   PQ_TRY(c->arena.get(size_t(nnz) + 1, &d_indices));
   PQ_TRY(c->arena.get(size_t(nnz) + 1, &d_vals));
-  hipLaunchKernelGGL(k_rows, gn, blk, 0, c->stream, N, d_vcount, d_ent, d_area, d_nnzrow, d_indices,
-                     d_vals, d_mass);
+  static const bool rows_wave = [] { const char* e = getenv("PYQSM_LAP_ROWS"); return !(e && e[0] == '0'); }();
+  if (rows_wave)
+    hipLaunchKernelGGL(k_rows_wave, dim3(ceil_div(n, 4)), blk, 0, c->stream, N, d_vcount, d_ent, d_area, d_nnzrow,
+                       d_indices, d_vals, d_mass);
+  else  // PYQSM_LAP_ROWS=0: a thread per row
+    hipLaunchKernelGGL(k_rows, gn, blk, 0, c->stream, N, d_vcount, d_ent, d_area, d_nnzrow, d_indices,
+                       d_vals, d_mass);
   PQ_HIP(hipGetLastError());
   out->indptr = d_nnzrow;
   out->indices = d_indices;
