@@ -489,10 +489,11 @@ __device__ __host__ inline int cover_halfedge(int code, bool fwd) {
 // run of equal mx cyclically.
 __global__ __launch_bounds__(256) void k_glue(int n, const int32_t* __restrict__ bstart,
                                               EdgeRec* __restrict__ rec,
-                                              int32_t* __restrict__ fn) {
+                                              int32_t* __restrict__ fn, int min_len) {
   int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const int b = bstart[i], e = bstart[i + 1];
+  if (e - b < min_len) return;  // k_glue_wave's
   for (int a = b + 1; a < e; ++a) {
     const EdgeRec x = rec[a];
     int j = a;
@@ -514,6 +515,50 @@ __global__ __launch_bounds__(256) void k_glue(int n, const int32_t* __restrict__
       fn[h2] = h1;
     }
     a = z;
+  }
+}
+
+// The same for buckets of at most 64 records (all but a handful), a wave per bucket: the records are
+// sorted in registers (bitonic network over the lanes, one 64-bit (mx, code) key each) instead of
+// by an insertion sort that shuffles them through global memory (2-3 ms per million points), and
+// every lane glues its record to the next of its run. k_glue then only takes the longer buckets
+// (min_len).
+__global__ __launch_bounds__(256) void k_glue_wave(int n, const int32_t* __restrict__ bstart,
+                                                   const EdgeRec* __restrict__ rec,
+                                                   int32_t* __restrict__ fn) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;  // whole waves
+  const int b = bstart[i], m = bstart[i + 1] - b;
+  if (m == 0 || m > 64) return;
+  unsigned long long key = ~0ull;
+  if (lane < m) {
+    const EdgeRec r = rec[b + lane];
+    key = ((unsigned long long)(unsigned)r.mx << 32) | (unsigned)r.code;  // both non-negative
+  }
+#pragma unroll
+  for (int k = 2; k <= 64; k <<= 1)
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const unsigned long long o = __shfl_xor(key, j, 64);
+      const bool up = (lane & k) == 0, lower = (lane & j) == 0;
+      key = (lower == up) ? (key < o ? key : o) : (key < o ? o : key);
+    }
+  const int mx = int(key >> 32), code = int(unsigned(key));
+  const bool valid = lane < m;  // the padding keys sort behind the records
+  const int prev_mx = __shfl_up(mx, 1, 64);
+  const unsigned long long heads = __ballot(valid && (lane == 0 || mx != prev_mx));
+  const unsigned long long upto = heads & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+  const unsigned long long later = lane == 63 ? 0ull : (heads & ~((2ull << lane) - 1ull));
+  const int first = 63 - __builtin_clzll(upto | 1ull);
+  const int end = later ? __ffsll(later) - 1 : m;
+  const int next = lane + 1 < end ? lane + 1 : first;  // cyclic inside the run
+  const int code_next = __shfl(code, next, 64);
+  if (valid) {
+    const int h1 = cover_halfedge(code, true);
+    const int h2 = cover_halfedge(code_next, false);
+    fn[h1] = h2;
+    fn[h2] = h1;
   }
 }
 
@@ -1186,7 +1231,9 @@ int laplacian_device(Ctx* c, const double* d_xyz, int64_t n, const int64_t* seg_
     PQ_TRY(exclusive_scan_i32(c, d_bcount, n + 1));
     hipLaunchKernelGGL(k_edge_scatter, gt, blk, 0, c->stream, T, d_tris, d_bcount, d_bcursor,
                        d_rec);
-    hipLaunchKernelGGL(k_glue, gn, blk, 0, c->stream, N, d_bcount, d_rec, d_fn);
+    hipLaunchKernelGGL(k_glue_wave, dim3(ceil_div(n, 4)), blk, 0, c->stream, N, d_bcount,
+                       static_cast<const EdgeRec*>(d_rec), d_fn);
+    hipLaunchKernelGGL(k_glue, gn, blk, 0, c->stream, N, d_bcount, d_rec, d_fn, 65);
     PQ_HIP(hipGetLastError());
     // intrinsic Delaunay flips: rounds of conflict-free flips until none is left
     ProfScope pf(c, "lap_flips");
