@@ -14,6 +14,7 @@ configuration.
 collective — and the ray stage shards its rays over the N GPUs through RCCL
 (cast_rays(..., n_devices=N) = pyqsm_cast_rays_multi)."""
 import argparse
+import gc
 import json
 from concurrent.futures import ThreadPoolExecutor
 import os
@@ -89,14 +90,18 @@ def main():
     else:
         with ThreadPoolExecutor(max_workers=max(1, args.workers) * n_gpus) as pool:
             shifts = list(pool.map(contract, enumerate(trees)))
+    gc.collect()      # the stage's page-locked result buffers go back now, not while the next stage is timed
     out["skeleton_s"] = time.perf_counter() - t0
     out["skeleton_trees"] = len(shifts)
     out["skeleton_workers"] = max(1, args.workers)
     out["mean_contraction_m"] = shifts
 
     t0 = time.perf_counter()
+    stage_t = {"slice": 0.0, "draw": 0.0, "fit": 0.0}
+
     def fit_slices(job):
         k, tree = job
+        ta = time.perf_counter()
         cloud = pts[tree]
         slices = []
         for z0 in np.arange(0.5, 5.5, 0.5):                 # 0.5 m slices of the stem
@@ -106,10 +111,15 @@ def main():
                 slices.append(sl.copy())
         if not slices:
             return []
+        tb = time.perf_counter()
+        stage_t["slice"] += tb - ta
         if args.ransac_batch:                               # all slices of the tree in one call
+            smp = [draw_samples(len(sl), 1000, seed=2) for sl in slices]
+            tc = time.perf_counter()
+            stage_t["draw"] += tc - tb
             fits = fit_shape_RANSAC_batch(slices, shape="circle", threshold=0.04, max_radius=0.3 * 1.75,
-                                          samples=[draw_samples(len(sl), 1000, seed=2) for sl in slices],
-                                          device=k % n_gpus)
+                                          samples=smp, device=k % n_gpus)
+            stage_t["fit"] += time.perf_counter() - tc
         else:
             fits = [fit_shape_RANSAC(pts=sl, shape="circle", threshold=0.04, max_radius=0.3 * 1.75,
                                      samples=draw_samples(len(sl), 1000, seed=2), device=k % n_gpus)
@@ -121,6 +131,7 @@ def main():
                  for r in found]
     fits = len(radii)
     out["ransac_s"] = time.perf_counter() - t0
+    out["ransac_thread_seconds"] = {k: round(v, 3) for k, v in stage_t.items()}
     out["ransac_fits"] = fits
     out["ransac_median_radius_m"] = float(np.median(radii)) if radii else None
 

@@ -161,22 +161,26 @@ void* out_alloc(size_t bytes) {
 
 void out_free(void* p) {
   if (!p) return;
+  bool pinned = false, unpin = false;
   {
     std::lock_guard<std::mutex> lk(g_pin_mu);
     auto it = pin_live().find(p);
     if (it != pin_live().end()) {
+      pinned = true;
       const size_t sz = it->second;
       pin_live().erase(it);
       if (g_pin_idle_bytes + sz <= kPinnedIdleCap) {
         pin_idle().emplace(sz, p);
         g_pin_idle_bytes += sz;
       } else {
-        (void)hipHostFree(p);
+        unpin = true;
       }
-      return;
     }
   }
-  free(p);
+  // unpinning hundreds of megabytes takes a tenth of a second: not under the lock every other
+  // thread's allocations wait on
+  if (unpin) (void)hipHostFree(p);
+  if (!pinned) free(p);
 }
 
 // ---- contexts -----------------------------------------------------------
