@@ -154,7 +154,9 @@ __global__ __launch_bounds__(256) void k_mis_max(int n, const int32_t* __restric
                                                  const double* __restrict__ vals,
                                                  const double* __restrict__ diag,
                                                  const unsigned long long* __restrict__ in,
-                                                 unsigned long long* __restrict__ out) {
+                                                 unsigned long long* __restrict__ out,
+                                                 const int32_t* __restrict__ prev_left) {
+  if (prev_left && *prev_left == 0) return;  // the selection finished in an earlier round of this batch
   int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   unsigned long long m = in[i];
@@ -173,7 +175,9 @@ __global__ __launch_bounds__(256) void k_mis_max(int n, const int32_t* __restric
 __global__ __launch_bounds__(256) void k_mis_update(int n, const unsigned long long* __restrict__ t2,
                                                     int32_t* __restrict__ state,
                                                     unsigned long long* __restrict__ key,
-                                                    int32_t* __restrict__ left) {
+                                                    int32_t* __restrict__ left,
+                                                    const int32_t* __restrict__ prev_left) {
+  if (prev_left && *prev_left == 0) return;  // (block-uniform; `left` of this round stays 0)
   int i = blockIdx.x * 256 + threadIdx.x;
   bool still = false;
   if (i < n && state[i] == kUndecided) {
@@ -850,18 +854,29 @@ static int aggregate(Ctx* c, AmgLevel& F, int32_t* d_counter, int* nc_out) {
   PQ_TRY(c->arena.get(size_t(n), &t2));
   hipLaunchKernelGGL(k_mis_init, g, blk, 0, c->stream, n, F.A.indptr, F.A.indices, F.A.vals, F.diag,
                      state, key);
-  for (int round = 0; round < 64; ++round) {
-    hipLaunchKernelGGL(k_mis_max, g, blk, 0, c->stream, n, F.A.indptr, F.A.indices, F.A.vals, F.diag,
-                       key, t1);
-    hipLaunchKernelGGL(k_mis_max, g, blk, 0, c->stream, n, F.A.indptr, F.A.indices, F.A.vals, F.diag,
-                       t1, t2);
-    PQ_HIP(hipMemsetAsync(d_counter, 0, 4, c->stream));
-    hipLaunchKernelGGL(k_mis_update, g, blk, 0, c->stream, n, t2, state, key, d_counter);
-    int32_t left = 0;
-    PQ_HIP(hipMemcpyAsync(&left, d_counter, 4, hipMemcpyDeviceToHost, c->stream));
+  // Rounds are queued kMisBatch at a time between two looks at the number of undecided points (a
+  // look is a round trip of ~25 us, a hierarchy has ~40 rounds); each round leaves its count in
+  // its own slot, and the kernels of a round whose predecessor left nobody undecided return at once.
+  static constexpr int kMisRounds = 64, kMisBatch = 4;
+  int32_t* left = nullptr;
+  PQ_TRY(c->arena.get(size_t(kMisRounds), &left));
+  PQ_HIP(hipMemsetAsync(left, 0, size_t(kMisRounds) * 4, c->stream));
+  (void)d_counter;
+  for (int round = 0;;) {
+    const int batch_end = std::min(round + kMisBatch, kMisRounds);
+    for (; round < batch_end; ++round) {
+      const int32_t* prev = round > 0 ? left + (round - 1) : nullptr;
+      hipLaunchKernelGGL(k_mis_max, g, blk, 0, c->stream, n, F.A.indptr, F.A.indices, F.A.vals, F.diag,
+                         key, t1, prev);
+      hipLaunchKernelGGL(k_mis_max, g, blk, 0, c->stream, n, F.A.indptr, F.A.indices, F.A.vals, F.diag,
+                         t1, t2, prev);
+      hipLaunchKernelGGL(k_mis_update, g, blk, 0, c->stream, n, t2, state, key, left + round, prev);
+    }
+    int32_t open = 0;
+    PQ_HIP(hipMemcpyAsync(&open, left + (round - 1), 4, hipMemcpyDeviceToHost, c->stream));
     PQ_HIP(hipStreamSynchronize(c->stream));
-    if (left == 0) break;
-    if (round == 63) return fail(PYQSM_EHIP, "multigrid: independent-set selection did not finish");
+    if (open == 0) break;
+    if (round >= kMisRounds) return fail(PYQSM_EHIP, "multigrid: independent-set selection did not finish");
   }
   PQ_HIP(hipMemsetAsync(flags + n, 0, 4, c->stream));
   hipLaunchKernelGGL(k_root_flags, g, blk, 0, c->stream, n, state, flags);
