@@ -1032,6 +1032,8 @@ static int lbc_solve_core(Ctx* c, const DevCsr& L, int64_t n, const double* wl, 
   PQ_TRY(c->arena.get(size_t(n) * 3, &b));
   PQ_TRY(c->arena.get(size_t(n), &minv_a));
   PQ_TRY(c->arena.get(size_t(3) * kPart, &d_tmp));
+  double* d_parts[5];  // the outer iteration's dot products of one step: launched one after the other, read in ONE look
+  for (int a = 0; a < 5; ++a) PQ_TRY(c->arena.get(size_t(3) * kPart, &d_parts[a]));
   hipLaunchKernelGGL(k_rhs, grid, block, 0, c->stream, N, wh, pts, b);
   PQ_HIP(hipMemcpyAsync(x, pts, size_t(n) * 24, hipMemcpyDeviceToDevice, c->stream));
   Work wa;
@@ -1284,10 +1286,10 @@ static int lbc_solve_core(Ctx* c, const DevCsr& L, int64_t n, const double* wl, 
   int outer = 0, best_outer = 0;
   bool done = std::max(resid[0], std::max(resid[1], resid[2])) <= rtol;
   // after every preconditioner application: error estimate of the current x
-  auto judge = [&]() -> int {
-    double zz[3], xx[3];
-    PQ_TRY(dot3_host(c, N, z, z, d_tmp, zz));
-    PQ_TRY(dot3_host(c, N, x, x, d_tmp, xx));
+  auto dot_launch = [&](const double* a, const double* bvec, double* part) {
+    hipLaunchKernelGGL(k_dot3, dim3(reduce_grid(N)), dim3(256), 0, c->stream, N, a, bvec, part);
+  };
+  auto judge = [&](const double zz[3], const double xx[3]) -> int {
     double est = 0.0;
     for (int k = 0; k < 3; ++k) est = std::max(est, xx[k] > 0 ? std::sqrt(zz[k] / xx[k]) : 0.0);
     if (trace)
@@ -1307,8 +1309,14 @@ static int lbc_solve_core(Ctx* c, const DevCsr& L, int64_t n, const double* wl, 
   auto restart = [&]() -> int {
     PQ_TRY(precond(r, z));
     PQ_HIP(hipMemcpyAsync(dir, z, size_t(n) * 24, hipMemcpyDeviceToDevice, c->stream));
-    PQ_TRY(dot3_host(c, N, r, z, d_tmp, rz));
-    if (judge() != 0) return fail(PYQSM_EHIP, "contraction solve: non-finite preconditioned residual");
+    dot_launch(r, z, d_parts[0]);
+    dot_launch(z, z, d_parts[1]);
+    dot_launch(x, x, d_parts[2]);
+    PQ_HIP(hipGetLastError());
+    double t[3][3];
+    PQ_TRY(part_totals_host(c, d_parts, 3, t));
+    for (int k = 0; k < 3; ++k) rz[k] = t[0][k];
+    if (judge(t[1], t[2]) != 0) return fail(PYQSM_EHIP, "contraction solve: non-finite preconditioned residual");
     return 0;
   };
   if (!done) {
@@ -1328,13 +1336,24 @@ static int lbc_solve_core(Ctx* c, const DevCsr& L, int64_t n, const double* wl, 
     }
     hipLaunchKernelGGL(k_axpy3, grid, block, 0, c->stream, N, alpha, dir, x);
     hipLaunchKernelGGL(k_axpy3, grid, block, 0, c->stream, N, nalpha, q, r);
-    PQ_TRY(dot3_host(c, N, r, r, d_tmp, rr));
     ++outer;
-    const double worst = rel(rr, cur_res);
-    if (!std::isfinite(worst)) break;
     PQ_HIP(hipMemcpyAsync(z_old, z, size_t(n) * 24, hipMemcpyDeviceToDevice, c->stream));
     PQ_TRY(precond(r, z));
-    const int jr = judge();
+    // the five dot products of the step in one look (each look is a round trip; they used to be
+    // five, plus the one for alpha above: 0.2 ms per outer step). |r|^2 is only needed for the
+    // report and the breakdown test, so it waits for the others.
+    dot_launch(r, r, d_parts[0]);
+    dot_launch(z, z, d_parts[1]);
+    dot_launch(x, x, d_parts[2]);
+    dot_launch(r, z, d_parts[3]);
+    dot_launch(r, z_old, d_parts[4]);
+    PQ_HIP(hipGetLastError());
+    double t5[5][3];
+    PQ_TRY(part_totals_host(c, d_parts, 5, t5));
+    for (int k = 0; k < 3; ++k) rr[k] = t5[0][k];
+    const double worst = rel(rr, cur_res);
+    if (!std::isfinite(worst)) break;
+    const int jr = judge(t5[1], t5[2]);
     if (jr < 0) return jr;
     if (jr > 0 || done) break;
     // attainable accuracy reached. Phase 1 leaves much sooner: its estimate flattens once what is
@@ -1347,9 +1366,8 @@ static int lbc_solve_core(Ctx* c, const DevCsr& L, int64_t n, const double* wl, 
     }();
     if (outer - best_outer >= (phase == 1 ? ric_stall : kOuterStall)) break;
     // flexible (Polak-Ribiere) beta: the inner solves are not exact
-    double rz_new[3], rzo[3];
-    PQ_TRY(dot3_host(c, N, r, z, d_tmp, rz_new));
-    PQ_TRY(dot3_host(c, N, r, z_old, d_tmp, rzo));
+    const double* rz_new = t5[3];
+    const double* rzo = t5[4];
     S3 beta;
     for (int k = 0; k < 3; ++k) {
       beta.v[k] = rz[k] != 0.0 ? (rz_new[k] - rzo[k]) / rz[k] : 0.0;
