@@ -421,7 +421,11 @@ static int fps_pruned(Ctx* c, const double* d_xyz, int N, int S, int start_index
     }
     // early: every bucket is in reach, one per wave; late: a block looks at 64 buckets' boxes
     // (late: 256 / 128 / 64 / 32 / 16 buckets per block -> 0.654 / 0.611 / 0.596 / 0.624 / 0.708 s for 100 k samples)
-    const int blocks = std::max(1, std::min(kMaxBlocks, ceil_div(int(nb), late ? 64 : 4)));
+    // (PYQSM_FPS_MAX_BLOCKS: a test hook — a small grid makes every block take several passes over its
+    // buckets, the path a cloud of more than 67 M points takes)
+    const char* mbe = getenv("PYQSM_FPS_MAX_BLOCKS");
+    const int max_blocks = mbe && atoi(mbe) > 0 ? std::min(atoi(mbe), kMaxBlocks) : kMaxBlocks;
+    const int blocks = std::max(1, std::min(max_blocks, ceil_div(int(nb), late ? 64 : 4)));
     const Far* cur = (s & 1) ? vb : va;
     Far* next = (s & 1) ? va : vb;
     const Far* pprev = (s & 1) ? pb : pa;

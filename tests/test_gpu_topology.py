@@ -85,6 +85,9 @@ def test_fps_pruned_rounds_match_oracle_and_whole_cloud_rounds(gpu, monkeypatch)
     a = hip.fps(Q, 40_000, 7, device=gpu)
     R = np.concatenate([P[:50_000], P[:50_000][::-1][:30_000]])                      # 30 000 exact copies
     b = hip.fps(R, len(R), 0, device=gpu)                                            # down to distance zero
+    monkeypatch.setenv("PYQSM_FPS_MAX_BLOCKS", "3")        # every block walks its buckets in several passes
+    assert np.array_equal(a[:6000], hip.fps(Q, 6000, 7, device=gpu))
+    monkeypatch.delenv("PYQSM_FPS_MAX_BLOCKS")
     monkeypatch.setenv("PYQSM_FPS_PRUNE", "0")
     assert np.array_equal(a, hip.fps(Q, 40_000, 7, device=gpu))
     assert np.array_equal(b, hip.fps(R, len(R), 0, device=gpu))
