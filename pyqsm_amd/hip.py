@@ -119,11 +119,12 @@ def cast_rays(verts, tris, rays, device: int = 0):
     return t_hit.reshape(lead), prim.reshape(lead), uv.reshape(lead + (2,))
 
 
-def cast_rays_multi(verts, tris, rays, n_devices: int = 0):
+def cast_rays_multi(verts, tris, rays, n_devices: int = 0, with_uv: bool = True):
     """The same closest-hit sweep on ``n_devices`` GPUs driven from this one process
     (``pyqsm_cast_rays_multi``: mesh replicated by RCCL broadcast, rays in contiguous shards,
     results all-gathered; 0 = every visible GPU). No torch involved. Returns what
-    :func:`cast_rays` returns, bit for bit."""
+    :func:`cast_rays` returns, bit for bit (``with_uv=False``: uv is None and half the bytes
+    are gathered)."""
     v, t = _mesh(verts, tris)
     r = np.ascontiguousarray(np.asarray(rays), dtype=np.float32)
     if r.shape[-1] != 6:
@@ -133,10 +134,11 @@ def cast_rays_multi(verts, tris, rays, n_devices: int = 0):
     R = r2.shape[0]
     t_hit = np.empty(R, dtype=np.float32)
     prim = np.empty(R, dtype=np.uint32)
-    uv = np.empty((R, 2), dtype=np.float32)
+    uv = np.empty((R, 2), dtype=np.float32) if with_uv else None
     check(_lib.load().pyqsm_cast_rays_multi(_p(v), v.shape[0], _p(t), t.shape[0], _p(r2), R,
-                                            _p(t_hit), _p(prim), _p(uv), int(n_devices)))
-    return t_hit.reshape(lead), prim.reshape(lead), uv.reshape(lead + (2,))
+                                            _p(t_hit), _p(prim), _p(uv) if with_uv else None,
+                                            int(n_devices)))
+    return t_hit.reshape(lead), prim.reshape(lead), uv.reshape(lead + (2,)) if with_uv else None
 
 
 def list_intersections(verts, tris, rays, device: int = 0):

@@ -5,18 +5,17 @@ records for 500 k triangles) and an all-gather of the per-shard results (8 bytes
 the sweep itself needs no exchange. DBSCAN / kNN / skeleton / RANSAC do
 not shard: replicas only.
 
-Three ways to run it, all with the same shard arithmetic (:func:`shard_bounds`):
+Two ways to run it, both with the same shard arithmetic (:func:`shard_bounds`):
 
 * one process, several GPUs: ``hip.cast_rays_multi`` / ``cast_rays(..., n_devices=N)`` —
-  RCCL inside the library (``ncclCommInitAll``), no torch;
+  RCCL inside the library (``ncclCommInitAll``);
 * one process per GPU (torchrun-style): :class:`NativeComm` — an RCCL communicator inside the
-  library per process, its id shipped through a rendezvous the caller provides (a file here,
-  or any ``torch.distributed`` group incl. CPU ``gloo``); every byte of the data path moves
-  through ``pyqsm_comm_*``;
-* any ``torch.distributed`` group (``gloo`` on CPU in the tests): :func:`broadcast_mesh` /
-  :func:`cast_rays_sharded`, generic over the per-shard compute function.
+  library per process, its id shipped through a rendezvous the caller provides (a private file
+  here, or any object with ``broadcast_object_list`` such as a CPU ``gloo`` group); every byte
+  of the data path moves through ``pyqsm_comm_*``.
 
-``torch`` is imported lazily and only by the functions that take a ``dist`` argument.
+Nothing here imports torch. With ``PYQSM_MULTI_FAKE_RANKS=N`` both run N logical ranks on one
+GPU (``csrc/multi.hip``): how the one-GPU test boxes execute the N > 1 orchestration.
 """
 from __future__ import annotations
 
@@ -36,57 +35,6 @@ def shard_bounds(n_items: int, world: int, rank: int):
 def shard_sizes(n_items: int, world: int):
     return [shard_bounds(n_items, world, r)[1] - shard_bounds(n_items, world, r)[0]
             for r in range(world)]
-
-
-def broadcast_mesh(verts, tris, dist, device=None, src: int = 0):
-    """Replicate (verts f32 [V,3], tris i32 [T,3]) from `src` to every rank.
-    Ranks other than `src` may pass None. Returns NumPy arrays on every rank."""
-    import torch
-    rank = dist.get_rank()
-    dev = device if device is not None else "cpu"
-    shape = torch.zeros(2, dtype=torch.int64, device=dev)
-    if rank == src:
-        verts = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 3)
-        tris = np.ascontiguousarray(tris, dtype=np.int32).reshape(-1, 3)
-        shape = torch.tensor([verts.shape[0], tris.shape[0]], dtype=torch.int64, device=dev)
-    dist.broadcast(shape, src=src)
-    V, T = (int(x) for x in shape.tolist())
-    tv = (torch.from_numpy(verts).to(dev) if rank == src
-          else torch.empty((V, 3), dtype=torch.float32, device=dev))
-    tt = (torch.from_numpy(tris).to(dev) if rank == src
-          else torch.empty((T, 3), dtype=torch.int32, device=dev))
-    dist.broadcast(tv, src=src)
-    dist.broadcast(tt, src=src)
-    return tv.cpu().numpy(), tt.cpu().numpy()
-
-
-def cast_rays_sharded(verts, tris, rays, dist, cast_fn, device=None):
-    """Closest-hit sweep of `rays` [R,6] (the same full array on every rank) with
-    each rank computing its contiguous shard through ``cast_fn(verts, tris,
-    rays_shard) -> (t_hit, prim_id, uv)`` and an all-gather assembling the full
-    result on every rank. Results are identical to a single-rank call because
-    rays are independent."""
-    import torch
-    world, rank = dist.get_world_size(), dist.get_rank()
-    dev = device if device is not None else "cpu"
-    rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)
-    R = rays.shape[0]
-    b, e = shard_bounds(R, world, rank)
-    t, p, uv = cast_fn(verts, tris, rays[b:e])
-    sizes = shard_sizes(R, world)
-    cap = max(sizes) if sizes else 0
-    # pack (t, prim, u, v) as 4 x 32-bit words per ray so one collective moves it all
-    packed = np.zeros((cap, 4), dtype=np.uint32)
-    packed[: e - b, 0] = np.asarray(t, dtype=np.float32).view(np.uint32)
-    packed[: e - b, 1] = np.asarray(p, dtype=np.uint32)
-    packed[: e - b, 2:] = np.asarray(uv, dtype=np.float32).reshape(-1, 2).view(np.uint32)
-    mine = torch.from_numpy(packed.view(np.int32)).to(dev)
-    parts = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(parts, mine)
-    full = np.concatenate([parts[r].cpu().numpy().view(np.uint32)[: sizes[r]]
-                           for r in range(world)], axis=0)
-    return (full[:, 0].copy().view(np.float32), full[:, 1].copy(),
-            full[:, 2:].copy().view(np.float32))
 
 
 # --------------------------------------------------------------------------------------
@@ -124,30 +72,46 @@ class NativeComm:
         return cls(box[0], world, rank, device)
 
     @classmethod
-    def from_env(cls, device=None, directory: str = "/tmp", timeout_s: float = 120.0):
-        """File rendezvous for single-node launches: rank 0 writes the id to a file named after
-        the launcher's pid and MASTER_PORT, the other ranks wait for it."""
+    def from_env(cls, device=None, directory: str | None = None, timeout_s: float = 120.0):
+        """File rendezvous for single-node launches: rank 0 writes the id into a file that only
+        this user can have created, the other ranks wait for it.
+
+        The file lives in ``directory`` (default: ``$XDG_RUNTIME_DIR``, else the temp directory),
+        is named after the launcher's pid, MASTER_PORT and TORCHELASTIC_RUN_ID, is created with
+        ``O_CREAT | O_EXCL | O_NOFOLLOW`` and mode 0600 (a planted symlink or a foreign file makes
+        rank 0 fail instead of writing through it), and carries — after the 128 id bytes — the
+        launcher's start time as a nonce, so a file left behind by an earlier launch with the
+        same pid and port is never accepted. Prefer :meth:`from_torch` when a process group exists."""
         import os
+        import struct
+        import tempfile
         import time
         rank = int(os.environ.get("RANK", "0"))
         world = int(os.environ.get("WORLD_SIZE", "1"))
         if device is None:
             device = int(os.environ.get("LOCAL_RANK", str(rank)))
-        path = os.path.join(directory, "pyqsm_comm_%d_%s.id" % (os.getppid(),
-                                                                os.environ.get("MASTER_PORT", "0")))
+        if directory is None:
+            directory = os.environ.get("XDG_RUNTIME_DIR") or tempfile.gettempdir()
+        run_id = "".join(ch for ch in os.environ.get("TORCHELASTIC_RUN_ID", "") if ch.isalnum())[:32]
+        path = os.path.join(directory, "pyqsm_comm_%d_%s_%s.id" % (
+            os.getppid(), os.environ.get("MASTER_PORT", "0"), run_id or "norun"))
+        nonce = struct.pack("<d", _process_start_time(os.getppid()))
         if rank == 0:
-            tmp = path + ".tmp"
-            with open(tmp, "wb") as f:
-                f.write(cls.new_id())
+            tmp = "%s.%d.tmp" % (path, os.getpid())
+            for stale in (tmp, path):
+                try:
+                    os.unlink(stale)                     # removes a link, never its target
+                except FileNotFoundError:
+                    pass
+            fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL | os.O_NOFOLLOW, 0o600)
+            with os.fdopen(fd, "wb") as f:
+                f.write(cls.new_id() + nonce)
             os.replace(tmp, path)                       # atomic: readers never see a partial id
         t0 = time.time()
         while True:
-            # a file left by an earlier launch with the same pid and port is older than this
-            # launcher's children: ignore anything written before this process started - 5 min
-            if os.path.exists(path) and os.path.getsize(path) == 128 and \
-                    os.path.getmtime(path) > _process_start_time() - 300:
-                with open(path, "rb") as f:
-                    id_bytes = f.read()
+            id_bytes = _read_private(path, 128 + len(nonce))
+            if id_bytes is not None and id_bytes[128:] == nonce:
+                id_bytes = id_bytes[:128]
                 break
             if time.time() - t0 > timeout_s:
                 raise TimeoutError(f"no RCCL id at {path} after {timeout_s} s")
@@ -181,17 +145,34 @@ class NativeComm:
         self._lib.pyqsm_comm_finalize()
 
 
-def _process_start_time() -> float:
+def _process_start_time(pid=None) -> float:
+    """Start of process `pid` (default: this one) in seconds since boot; 0.0 when /proc cannot say."""
     import os
-    import time
     try:
-        with open("/proc/self/stat") as f:
+        with open("/proc/%s/stat" % ("self" if pid is None else int(pid))) as f:
             ticks = int(f.read().rsplit(")", 1)[1].split()[19])
-        with open("/proc/uptime") as f:
-            up = float(f.read().split()[0])
-        return time.time() - up + ticks / os.sysconf("SC_CLK_TCK")
+        return ticks / os.sysconf("SC_CLK_TCK")
     except Exception:
-        return time.time()
+        return 0.0
+
+
+def _read_private(path: str, nbytes: int):
+    """The first `nbytes` of a regular file owned by this user that nobody else can write, opened
+    without following links; None when it is not (yet) there or not like that."""
+    import os
+    import stat
+    try:
+        fd = os.open(path, os.O_RDONLY | os.O_NOFOLLOW)
+    except OSError:
+        return None
+    try:
+        st = os.fstat(fd)
+        if not stat.S_ISREG(st.st_mode) or st.st_uid != os.getuid() or st.st_mode & 0o022 \
+                or st.st_size != nbytes:
+            return None
+        return os.read(fd, nbytes)
+    finally:
+        os.close(fd)
 
 
 class ShardedSweep:
@@ -208,20 +189,32 @@ class ShardedSweep:
         self.cap = max(self.sizes) if self.sizes else 0
         dev = comm.device
         T = int(np.asarray(tris).reshape(-1, 3).shape[0])
-        if comm.rank == 0:
-            self.mesh = hip.DeviceMesh(verts, tris, dev)
-        else:                                            # records arrive over RCCL
-            self.mesh = hip.DeviceMesh.__new__(hip.DeviceMesh)
-            self.mesh.device, self.mesh.n_tris = dev, T
-            self.mesh.records = hip.DeviceBuffer(max(1, T) * 48, dev)
+        # everything that can fail for local reasons (a triangle index outside the vertices on
+        # rank 0, a wrong shard size, no memory) comes BEFORE the first collective, and the ranks
+        # agree on "everybody can" first: a rank that raised here would otherwise leave the others
+        # waiting in the broadcast for good (the same hand-shake as pyqsm_cast_rays_multi)
+        err = None
+        try:
+            if comm.rank == 0:
+                self.mesh = hip.DeviceMesh(verts, tris, dev)
+            else:                                            # records arrive over RCCL
+                self.mesh = hip.DeviceMesh.__new__(hip.DeviceMesh)
+                self.mesh.device, self.mesh.n_tris = dev, T
+                self.mesh.records = hip.DeviceBuffer(max(1, T) * 48, dev)
+            rays_shard = np.ascontiguousarray(rays_shard, dtype=np.float32).reshape(-1, 6)
+            if rays_shard.shape[0] != self.sizes[comm.rank]:
+                raise ValueError("rays_shard does not have this rank's shard size")
+            self.n_local = rays_shard.shape[0]
+            self.d_rays = hip.DeviceBuffer.from_array(rays_shard, dev) if self.n_local else None
+            # one block of [t(cap) | prim(cap)] 32-bit words per rank
+            self.block = hip.DeviceBuffer(max(1, comm.world * 2 * self.cap * 4), dev)
+        except Exception as exc:                             # noqa: BLE001 - re-raised below
+            err = exc
+        if comm.max_over_ranks(0.0 if err is None else 1.0) != 0.0:
+            if err is not None:
+                raise err
+            raise RuntimeError("ShardedSweep: the setup failed on another rank")
         comm.broadcast(self.mesh.records, T * 48, root=0)
-        rays_shard = np.ascontiguousarray(rays_shard, dtype=np.float32).reshape(-1, 6)
-        if rays_shard.shape[0] != self.sizes[comm.rank]:
-            raise ValueError("rays_shard does not have this rank's shard size")
-        self.n_local = rays_shard.shape[0]
-        self.d_rays = hip.DeviceBuffer.from_array(rays_shard, dev) if self.n_local else None
-        # one block of [t(cap) | prim(cap)] 32-bit words per rank
-        self.block = hip.DeviceBuffer(max(1, comm.world * 2 * self.cap * 4), dev)
         hip.sync(dev)
 
     def run(self) -> None:

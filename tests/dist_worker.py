@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import oracle  # noqa: E402
 from pyqsm_amd import synth  # noqa: E402
-from pyqsm_amd.parallel import broadcast_mesh, cast_rays_sharded  # noqa: E402
+from tests.dist_helpers import broadcast_mesh, cast_rays_sharded  # noqa: E402
 
 
 def main():

@@ -107,15 +107,14 @@ def _assert_invariants(P, bounds, got, total, steps, records, masses, iters):
     assert len(steps) == iters and len(got.solve_log) == iters
     assert len(masses) == iters + 1 and min(masses) > 0.0
     checked = [r for r in records if "cert" in r]
-    # No solve may end in PYQSM_ENOCONV while its system is well posed in fp64. On the collapsed
-    # cloud of the last contractions (rounding floor of the residual evaluation itself above
-    # ILL_POSED_FLOOR) the stagnation stop can fire — 1 of 9 runs at 1 M points, c = 7, always in
-    # the 20th solve — and the best iterate is what any fp64 solver could return there.
+    # No solve ends in PYQSM_ENOCONV. The loop is bit-reproducible since round 2 (no fp atomics in
+    # the reductions, stable-sorted unknowns), so this count is a constant of the configuration, not
+    # a rate: 0 for every configuration this file runs (20 k / 50 k / 1 M points, c = 3 and 7;
+    # measured again in round 3). Round 1's allowance of one stagnation stop on the collapsed cloud
+    # of the 20th contraction dated from the run-to-run spread of the atomics.
     bad = [k for k, q in enumerate(got.solve_log) if not q["ok"]]
     print("solves that ended in ENOCONV:", bad)
-    assert len(bad) <= 1
-    for k in bad:
-        assert records[k]["floor"] > ILL_POSED_FLOOR, (k, got.solve_log[k], records[k])
+    assert bad == [], [(k, got.solve_log[k], records[k]) for k in bad]
     print("step  cert      |r|/|b|   floor     uniform_wh")
     for r in checked:
         print(f"{r['step']:4d}  {r['cert']:.2e}  {r['resid']:.2e}  {r['floor']:.2e}  {r['uniform_wh']}")
