@@ -7,3 +7,5 @@ putting this directory on ``sys.path`` gives ``from math_utils.fit import
 cluster_DBSCAN`` etc. the HIP implementation.
 """
 __version__ = "0.1.0"
+
+from ._shadow import install  # noqa: E402,F401  (patch the HIP wrappers into an imported pyQSM)

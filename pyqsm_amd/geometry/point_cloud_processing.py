@@ -12,6 +12,7 @@ import numpy as np
 
 try:
     from .. import hip
+    from .._shadow import fall_through
     from ..set_config import config, log
     from .cloud import PointCloud, as_points
 except ImportError:  # flat import (pyqsm_amd/ on sys.path)
@@ -19,8 +20,12 @@ except ImportError:  # flat import (pyqsm_amd/ on sys.path)
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
     from pyqsm_amd import hip
+    from pyqsm_amd._shadow import fall_through
     from pyqsm_amd.set_config import config, log
     from pyqsm_amd.geometry.cloud import PointCloud, as_points
+
+# names pyQSM's module of the same name defines and this one does not (pyqsm_amd/_shadow.py)
+__getattr__ = fall_through(__name__)
 
 
 def _select(pcd, pts, idx):

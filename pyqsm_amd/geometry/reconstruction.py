@@ -6,13 +6,18 @@ import numpy as np
 
 try:
     from .. import hip
+    from .._shadow import fall_through
     from .cloud import PointCloud, as_points
 except ImportError:  # flat import (pyqsm_amd/ on sys.path)
     import os
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
     from pyqsm_amd import hip
+    from pyqsm_amd._shadow import fall_through
     from pyqsm_amd.geometry.cloud import PointCloud, as_points
+
+# names pyQSM's module of the same name defines and this one does not (pyqsm_amd/_shadow.py)
+__getattr__ = fall_through(__name__)
 
 
 def get_neighbors_kdtree(src_pcd, query_pcd=None, query_pts=None, kd_tree=None, dist=0.05, k=500,

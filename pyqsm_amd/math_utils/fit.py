@@ -19,6 +19,7 @@ import numpy as np
 
 try:
     from .. import hip
+    from .._shadow import fall_through
     from ..geometry.cloud import Cylinder, PointCloud, as_points
     from ..set_config import config, log
     from .general import get_radius, rotation_matrix_from_arr, unit_vector
@@ -27,9 +28,13 @@ except ImportError:  # imported flat, with pyqsm_amd/ itself on sys.path (pyQSM'
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
     from pyqsm_amd import hip
+    from pyqsm_amd._shadow import fall_through
     from pyqsm_amd.geometry.cloud import Cylinder, PointCloud, as_points
     from pyqsm_amd.set_config import config, log
     from pyqsm_amd.math_utils.general import get_radius, rotation_matrix_from_arr, unit_vector
+
+# names pyQSM's module of the same name defines and this one does not (pyqsm_amd/_shadow.py)
+__getattr__ = fall_through(__name__)
 
 # pyransac3d's default iteration counts (Circle.fit / Cylinder.fit signatures)
 DEFAULT_ITERATIONS = {"circle": 1000, "cylinder": 10000}

@@ -6,6 +6,17 @@ from __future__ import annotations
 
 import numpy as np
 
+try:
+    from .._shadow import fall_through
+except ImportError:  # imported flat, with pyqsm_amd/ itself on sys.path (pyQSM's layout)
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    from pyqsm_amd._shadow import fall_through
+
+# names pyQSM's module of the same name defines and this one does not: get_angles, ... (pyqsm_amd/_shadow.py)
+__getattr__ = fall_through(__name__)
+
 
 def get_percentile(pts, low, high, axis=2, invert=False):
     """Indices (and values) strictly between the low and high percentiles of one

@@ -11,6 +11,7 @@ import logging
 import numpy as np
 
 try:  # flat import style of the reference (pyqsm_amd on sys.path) or package import
+    from ._shadow import fall_through
     from .math_utils.fit import fit_shape_RANSAC
     from .math_utils.general import get_center
     from .set_config import config
@@ -18,9 +19,13 @@ except ImportError:  # pragma: no cover
     import os
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from pyqsm_amd._shadow import fall_through
     from pyqsm_amd.math_utils.fit import fit_shape_RANSAC
     from pyqsm_amd.math_utils.general import get_center
     from pyqsm_amd.set_config import config
+
+# names pyQSM's module of the same name defines and this one does not (pyqsm_amd/_shadow.py)
+__getattr__ = fall_through(__name__)
 
 log = logging.getLogger("calc")
 

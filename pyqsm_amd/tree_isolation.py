@@ -20,13 +20,18 @@ import numpy as np
 
 try:  # flat import style of the reference (pyqsm_amd on sys.path) or package import
     from . import hip
+    from ._shadow import fall_through
     from .geometry.cloud import PointCloud, as_points
 except ImportError:  # pragma: no cover
     import os
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from pyqsm_amd import hip
+    from pyqsm_amd._shadow import fall_through
     from pyqsm_amd.geometry.cloud import PointCloud, as_points
+
+# names pyQSM's module of the same name defines and this one does not (pyqsm_amd/_shadow.py)
+__getattr__ = fall_through(__name__)
 
 log = logging.getLogger("calc")
 

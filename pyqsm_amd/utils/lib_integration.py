@@ -14,6 +14,7 @@ import numpy as np
 
 try:
     from .. import hip
+    from .._shadow import fall_through
     from ..geometry.cloud import as_points
     from ..math_utils.general import get_center, get_percentile, get_radius
     from ..set_config import config, log
@@ -22,9 +23,13 @@ except ImportError:  # flat import (pyqsm_amd/ on sys.path)
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
     from pyqsm_amd import hip
+    from pyqsm_amd._shadow import fall_through
     from pyqsm_amd.geometry.cloud import as_points
     from pyqsm_amd.math_utils.general import get_center, get_percentile, get_radius
     from pyqsm_amd.set_config import config, log
+
+# names pyQSM's module of the same name defines and this one does not (pyqsm_amd/_shadow.py)
+__getattr__ = fall_through(__name__)
 
 
 class Sphere:

@@ -21,6 +21,7 @@ import numpy as np
 
 try:
     from .. import hip
+    from .._shadow import fall_through
     from ..geometry.cloud import PointCloud, TriangleMesh
     from ..set_config import log
 except ImportError:  # flat import (pyqsm_amd/ on sys.path)
@@ -28,8 +29,12 @@ except ImportError:  # flat import (pyqsm_amd/ on sys.path)
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
     from pyqsm_amd import hip
+    from pyqsm_amd._shadow import fall_through
     from pyqsm_amd.geometry.cloud import PointCloud, TriangleMesh
     from pyqsm_amd.set_config import log
+
+# names pyQSM's module of the same name defines and this one does not (pyqsm_amd/_shadow.py)
+__getattr__ = fall_through(__name__)
 
 pinhole_config = {"fov_deg": 60, "center": [-3, -.25, -3], "eye": [10, 10, 20], "up": [0, 0, 1],
                   "width_px": 640, "height_px": 480}       # ray_casting.py:45-47
