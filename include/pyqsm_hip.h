@@ -190,6 +190,19 @@ int pyqsm_dbscan(const double* xyz, int64_t n, double eps, int32_t min_pts,
 int pyqsm_dbscan_dev(const double* xyz_dev, int64_t n, double eps, int32_t min_pts,
                      int64_t* labels_dev, uint8_t* is_core_dev, int64_t* n_clusters,
                      int32_t device);
+/*
+ * The same with the neighbourhood's boundary as a parameter. radius_inclusive != 0:
+ * d2 <= eps*eps, scikit-learn's (the two calls above). radius_inclusive == 0: d2 < eps*eps —
+ * what open3d cluster_dbscan (pyQSM/geometry/point_cloud_processing.py:185,209) computes if
+ * nanoflann's radius search compares strictly (Open3D is not installable
+ * here, so which of the two it is stays unpinned: this is the switch for whoever can check).
+ * Everything else — self counted, numbering, border rule — is unchanged.
+ */
+int pyqsm_dbscan_ex(const double* xyz, int64_t n, double eps, int32_t min_pts,
+                    int32_t radius_inclusive, int64_t* labels, uint8_t* is_core, int32_t device);
+int pyqsm_dbscan_dev_ex(const double* xyz_dev, int64_t n, double eps, int32_t min_pts,
+                        int32_t radius_inclusive, int64_t* labels_dev, uint8_t* is_core_dev,
+                        int64_t* n_clusters, int32_t device);
 
 /* ---- k nearest neighbours --------------------------------------------- */
 /*

@@ -45,6 +45,8 @@ def _lib():
         p = ctypes.c_void_p
         lib.orc_dbscan.restype = i64
         lib.orc_dbscan.argtypes = [p, i64, dbl, i32, p, p]
+        lib.orc_dbscan_strict.restype = i64
+        lib.orc_dbscan_strict.argtypes = [p, i64, dbl, i32, p, p]
         lib.orc_knn.restype = ctypes.c_int
         lib.orc_knn.argtypes = [p, i64, i32, i32, p, p]
         lib.orc_cast_rays.restype = ctypes.c_int
@@ -77,13 +79,15 @@ def _ptr(a):
 # --------------------------------------------------------------------------
 # DBSCAN  (sklearn.cluster.DBSCAN as called at pyQSM/math_utils/fit.py:223)
 
-def dbscan(points, eps, min_pts):
-    """labels int64 [n] (-1 = noise), core mask bool [n]."""
+def dbscan(points, eps, min_pts, radius_inclusive=True):
+    """labels int64 [n] (-1 = noise), core mask bool [n]. ``radius_inclusive=False``: the strict
+    neighbourhood d2 < eps^2 (Open3D's compare if nanoflann's is strict; parity unpinned)."""
     pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
     n = pts.shape[0]
     labels = np.empty(n, dtype=np.int64)
     core = np.zeros(n, dtype=np.uint8)
-    rc = _lib().orc_dbscan(_ptr(pts), n, float(eps), int(min_pts), _ptr(labels), _ptr(core))
+    fn = _lib().orc_dbscan if radius_inclusive else _lib().orc_dbscan_strict
+    rc = fn(_ptr(pts), n, float(eps), int(min_pts), _ptr(labels), _ptr(core))
     if rc < 0:
         raise MemoryError("orc_dbscan")
     return labels, core.astype(bool)

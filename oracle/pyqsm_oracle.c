@@ -123,8 +123,8 @@ static inline double sqdist(const double* a, const double* b) {
  *           points seed a depth-first expansion; a popped point takes the label
  *           if it has none; only core points push their unlabelled neighbours.
  */
-int64_t orc_dbscan(const double* xyz, int64_t n, double eps, int32_t min_pts, int64_t* labels,
-                   uint8_t* is_core) {
+static int64_t dbscan_impl(const double* xyz, int64_t n, double eps, int32_t min_pts, int strict,
+                           int64_t* labels, uint8_t* is_core) {
   if (n == 0) return 0;
   grid_t g;
   /* cell a hair wider than eps so that rounding in the cell index can never
@@ -157,7 +157,8 @@ int64_t orc_dbscan(const double* xyz, int64_t n, double eps, int32_t min_pts, in
           int64_t row = (z * g.dim[1] + y) * g.dim[0];
           for (int64_t s = g.start[row + x0]; s < g.start[row + x1 + 1]; ++s) {
             int64_t j = g.order[s];
-            if (sqdist(p, xyz + 3 * j) <= r2) {
+            const double d2 = sqdist(p, xyz + 3 * j);
+            if (strict ? d2 < r2 : d2 <= r2) {
               if (pass == 1) nbr[w++] = (int32_t)j;
               ++cnt;
             }
@@ -196,6 +197,21 @@ int64_t orc_dbscan(const double* xyz, int64_t n, double eps, int32_t min_pts, in
   free(nstart);
   grid_free(&g);
   return label_num;
+}
+
+/* scikit-learn's neighbourhood: d2 <= eps^2 (radius_neighbors is inclusive) */
+int64_t orc_dbscan(const double* xyz, int64_t n, double eps, int32_t min_pts, int64_t* labels,
+                   uint8_t* is_core) {
+  return dbscan_impl(xyz, n, eps, min_pts, 0, labels, is_core);
+}
+
+/* The same clustering with the STRICT neighbourhood d2 < eps^2: what Open3D's cluster_dbscan
+ * (pyQSM/geometry/point_cloud_processing.py:185,209) does if nanoflann's radius search compares
+ * strictly, as SURVEY.md §8 a2 suspects. Open3D is not installable here: PARITY UNPINNED, this
+ * is the switch a maintainer with Open3D at hand can flip (pyqsm_dbscan_ex, radius_inclusive = 0). */
+int64_t orc_dbscan_strict(const double* xyz, int64_t n, double eps, int32_t min_pts, int64_t* labels,
+                          uint8_t* is_core) {
+  return dbscan_impl(xyz, n, eps, min_pts, 1, labels, is_core);
 }
 
 /* ------------------------------------------------------------------------ */

@@ -51,6 +51,8 @@ SIGNATURES = {
     "pyqsm_comm_all_reduce_max": (ctypes.c_int, [ctypes.POINTER(dbl)]),
     "pyqsm_dbscan": (ctypes.c_int, [vp, i64, dbl, i32, vp, vp, i32]),
     "pyqsm_dbscan_dev": (ctypes.c_int, [vp, i64, dbl, i32, vp, vp, ctypes.POINTER(i64), i32]),
+    "pyqsm_dbscan_ex": (ctypes.c_int, [vp, i64, dbl, i32, i32, vp, vp, i32]),
+    "pyqsm_dbscan_dev_ex": (ctypes.c_int, [vp, i64, dbl, i32, i32, vp, vp, ctypes.POINTER(i64), i32]),
     "pyqsm_knn": (ctypes.c_int, [vp, i64, i32, i32, vp, vp, i32]),
     "pyqsm_knn_dev": (ctypes.c_int, [vp, i64, i32, i32, vp, vp, i32]),
     "pyqsm_ransac": (ctypes.c_int, [vp, i64, vp, i64, i32, dbl, vp, vp, ctypes.POINTER(dbl), vp,

@@ -707,7 +707,7 @@ __global__ __launch_bounds__(256) void k_labels_border(const int32_t* __restrict
 }
 
 static int dbscan_device(Ctx* c, const double* xyz, int64_t n, double eps, int32_t min_pts,
-                         int64_t* labels, uint8_t* is_core, int64_t* n_clusters) {
+                         bool radius_inclusive, int64_t* labels, uint8_t* is_core, int64_t* n_clusters) {
   if (!(eps > 0) || !std::isfinite(eps)) return fail(PYQSM_EINVAL, "eps must be positive");
   if (n == 0) {
     if (n_clusters) *n_clusters = 0;
@@ -732,7 +732,11 @@ static int dbscan_device(Ctx* c, const double* xyz, int64_t n, double eps, int32
   const int N = int(n);
   const dim3 grid(ceil_div(n, 256)), block(256);
   const Stencil st{g.nx, g.nx * g.ny};
-  const double r2 = eps * eps;
+  // Every kernel tests d2 <= r2. The STRICT neighbourhood d2 < eps^2 (radius_inclusive = 0: what
+  // Open3D's cluster_dbscan computes if nanoflann's radius search compares strictly; SURVEY.md
+  // §8 a2) is the same test against the double just below eps^2 — no fp64 value lies between
+  // the two, so d2 < r2 <=> d2 <= pred(r2) exactly, and the kernels need no second form.
+  const double r2 = radius_inclusive ? eps * eps : nextafter(eps * eps, 0.0);
   uint8_t* core;
   int *parent, *min_orig;
   int32_t* flag;
@@ -848,9 +852,9 @@ using namespace pyqsm;
 
 extern "C" {
 
-int pyqsm_dbscan_dev(const double* xyz_dev, int64_t n, double eps, int32_t min_pts,
-                     int64_t* labels_dev, uint8_t* is_core_dev, int64_t* n_clusters,
-                     int32_t device) {
+int pyqsm_dbscan_dev_ex(const double* xyz_dev, int64_t n, double eps, int32_t min_pts,
+                        int32_t radius_inclusive, int64_t* labels_dev, uint8_t* is_core_dev,
+                        int64_t* n_clusters, int32_t device) {
   PQ_API_RANGE("pyqsm_dbscan_dev");
   if (n < 0) return fail(PYQSM_EINVAL, "negative size");
   if (n > 0 && (!xyz_dev || !labels_dev)) return fail(PYQSM_EINVAL, "pyqsm_dbscan_dev: NULL pointer");
@@ -859,11 +863,23 @@ int pyqsm_dbscan_dev(const double* xyz_dev, int64_t n, double eps, int32_t min_p
   std::lock_guard<std::mutex> lk(c->mu);
   c->arena.reset();
   ProfScope ps(c, "dbscan_total");
-  return dbscan_device(c, xyz_dev, n, eps, min_pts, labels_dev, is_core_dev, n_clusters);
+  return dbscan_device(c, xyz_dev, n, eps, min_pts, radius_inclusive != 0, labels_dev, is_core_dev,
+                       n_clusters);
+}
+
+int pyqsm_dbscan_dev(const double* xyz_dev, int64_t n, double eps, int32_t min_pts,
+                     int64_t* labels_dev, uint8_t* is_core_dev, int64_t* n_clusters,
+                     int32_t device) {
+  return pyqsm_dbscan_dev_ex(xyz_dev, n, eps, min_pts, 1, labels_dev, is_core_dev, n_clusters, device);
 }
 
 int pyqsm_dbscan(const double* xyz, int64_t n, double eps, int32_t min_pts, int64_t* labels,
                  uint8_t* is_core, int32_t device) {
+  return pyqsm_dbscan_ex(xyz, n, eps, min_pts, 1, labels, is_core, device);
+}
+
+int pyqsm_dbscan_ex(const double* xyz, int64_t n, double eps, int32_t min_pts, int32_t radius_inclusive,
+                    int64_t* labels, uint8_t* is_core, int32_t device) {
   PQ_API_RANGE("pyqsm_dbscan");
   if (n < 0) return fail(PYQSM_EINVAL, "negative size");
   if (n == 0) return 0;
@@ -879,7 +895,7 @@ int pyqsm_dbscan(const double* xyz, int64_t n, double eps, int32_t min_pts, int6
   PQ_TRY(c->arena.get(size_t(n), &d_lab));
   PQ_TRY(c->arena.get(size_t(n), &d_core));
   PQ_HIP(hipMemcpyAsync(d_xyz, xyz, size_t(n) * 24, hipMemcpyHostToDevice, c->stream));
-  PQ_TRY(dbscan_device(c, d_xyz, n, eps, min_pts, d_lab, d_core, nullptr));
+  PQ_TRY(dbscan_device(c, d_xyz, n, eps, min_pts, radius_inclusive != 0, d_lab, d_core, nullptr));
   PQ_HIP(hipMemcpyAsync(labels, d_lab, size_t(n) * 8, hipMemcpyDeviceToHost, c->stream));
   if (is_core) PQ_HIP(hipMemcpyAsync(is_core, d_core, size_t(n), hipMemcpyDeviceToHost, c->stream));
   PQ_HIP(hipStreamSynchronize(c->stream));

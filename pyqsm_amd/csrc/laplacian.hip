@@ -430,6 +430,35 @@ __global__ __launch_bounds__(256) void k_tri_eps(int T, int S, const int32_t* __
   eps_tri[t] = eps_seg[lo];
 }
 
+// Batch builds (several clouds stacked into one array): the Laplacian of the union is block
+// diagonal only if every point finds its k neighbours inside its OWN cloud. A cloud with <= k
+// points, or one whose k-th own neighbour is farther away than the next cloud, would take
+// neighbours across the gap, its fans would span clouds, and the per-cloud weights would act on
+// a coupled system: caught here, before anything is built on it. bad[0] = 1 and bad[1] = the
+// smallest offending point index.
+__global__ __launch_bounds__(256) void k_check_segments(int n, int k, int S,
+                                                        const int32_t* __restrict__ seg_start,
+                                                        const int32_t* __restrict__ nbr,
+                                                        int32_t* __restrict__ bad) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  int lo = 0, hi = S;  // largest s with seg_start[s] <= i
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (seg_start[mid] <= i) lo = mid; else hi = mid;
+  }
+  const int b = seg_start[lo], e = seg_start[lo + 1];
+  bool ok = true;
+  for (int j = 0; j < k; ++j) {
+    const int q = nbr[size_t(i) * k + j];
+    ok = ok && q >= b && q < e;
+  }
+  if (!ok) {
+    bad[0] = 1;
+    atomicMin(&bad[1], i);
+  }
+}
+
 __global__ __launch_bounds__(256) void k_cover_init(int T, const int32_t* __restrict__ tris,
                                                     const double* __restrict__ len,
                                                     const double* __restrict__ eps_p,
@@ -1136,6 +1165,19 @@ int laplacian_device(Ctx* c, const double* d_xyz, int64_t n, const int64_t* seg_
     ProfScope ps(c, "lap_knn");
     PQ_TRY(knn_device(c, d_xyz, n, k, 1, d_nbr, d_d2));
   }
+  int32_t *d_seg_start = nullptr, *d_seg_bad = nullptr;
+  std::vector<int32_t> h_seg(size_t(n_seg) + 1), h_bad(2, 0);
+  if (n_seg > 1) {  // the clouds of a batch must not see each other (k_check_segments)
+    PQ_TRY(c->arena.get(size_t(n_seg) + 1, &d_seg_start));
+    PQ_TRY(c->arena.get(2, &d_seg_bad));
+    for (int64_t q = 0; q <= n_seg; ++q) h_seg[size_t(q)] = int32_t(seg_start[q]);
+    h_bad[1] = 0x7fffffff;
+    PQ_HIP(hipMemcpyAsync(d_seg_start, h_seg.data(), (size_t(n_seg) + 1) * 4, hipMemcpyHostToDevice, c->stream));
+    PQ_HIP(hipMemcpyAsync(d_seg_bad, h_bad.data(), 8, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_check_segments, dim3(ceil_div(n, 256)), dim3(256), 0, c->stream, N, k, int(n_seg),
+                       d_seg_start, d_nbr, d_seg_bad);
+    PQ_HIP(hipGetLastError());
+  }
   int32_t *d_tri, *d_tcount;
   PQ_TRY(c->arena.get(size_t(n) * k * 2, &d_tri));
   PQ_TRY(c->arena.get(size_t(n) + 1, &d_tcount));
@@ -1158,7 +1200,17 @@ int laplacian_device(Ctx* c, const double* d_xyz, int64_t n, const int64_t* seg_
   PQ_TRY(exclusive_scan_i32(c, d_tcount, n + 1));
   int32_t T = 0;
   PQ_HIP(hipMemcpyAsync(&T, d_tcount + n, 4, hipMemcpyDeviceToHost, c->stream));
+  if (n_seg > 1) PQ_HIP(hipMemcpyAsync(h_bad.data(), d_seg_bad, 8, hipMemcpyDeviceToHost, c->stream));
   PQ_HIP(hipStreamSynchronize(c->stream));
+  if (n_seg > 1 && h_bad[0] != 0) {
+    int64_t sidx = 0;
+    while (sidx + 1 < n_seg && seg_start[sidx + 1] <= h_bad[1]) ++sidx;
+    return fail(PYQSM_EINVAL,
+                "batched Laplacian: point %d of cloud %lld (%lld points) has one of its %d nearest neighbours in "
+                "another cloud - a cloud of a batch needs more than k points and a gap to the others wider than "
+                "its own diameter (send it through the single-cloud call)",
+                int(h_bad[1]), (long long)sidx, (long long)(seg_start[sidx + 1] - seg_start[sidx]), int(k));
+  }
   int32_t *d_tris, *d_vcount, *d_cursor, *d_nnzrow, *d_fv, *d_fn, *d_bcount, *d_bcursor,
       *d_cnt, *d_mark, *d_list[2];
   unsigned long long* d_claim;
@@ -1208,21 +1260,15 @@ int laplacian_device(Ctx* c, const double* d_xyz, int64_t n, const int64_t* seg_
                      d_blk_sum, d_blk_slack, moll, d_eps);
   double* d_eps_tri = nullptr;
   if (T > 0 && n_seg > 1) {  // one mollification length per cloud of the batch
-    int32_t *d_seg_start, *d_tstart;
+    int32_t* d_tstart;
     double* d_eps_seg;
-    PQ_TRY(c->arena.get(size_t(n_seg) + 1, &d_seg_start));
     PQ_TRY(c->arena.get(size_t(n_seg) + 1, &d_tstart));
     PQ_TRY(c->arena.get(size_t(n_seg), &d_eps_seg));
     PQ_TRY(c->arena.get(size_t(T), &d_eps_tri));
-    std::vector<int32_t> h32(size_t(n_seg) + 1);
-    for (int64_t q = 0; q <= n_seg; ++q) h32[size_t(q)] = int32_t(seg_start[q]);
-    PQ_HIP(hipMemcpyAsync(d_seg_start, h32.data(), (size_t(n_seg) + 1) * 4, hipMemcpyHostToDevice,
-                          c->stream));
     hipLaunchKernelGGL(k_seg_eps, dim3(unsigned(n_seg)), blk, 0, c->stream, int(n_seg), d_seg_start, d_tcount,
                        d_len, moll, d_tstart, d_eps_seg);
     hipLaunchKernelGGL(k_tri_eps, gt, blk, 0, c->stream, T, int(n_seg), d_tstart, d_eps_seg, d_eps_tri);
     PQ_HIP(hipGetLastError());
-    PQ_HIP(hipStreamSynchronize(c->stream));  // h32 goes out of scope
   }
   if (T > 0) {
     // tufted cover: two faces per triangle, glued around every edge

@@ -392,9 +392,10 @@ static void apply_op(Ctx* c, const System& S, const Work& w, const double* v, do
   }
 }
 
-// Plain launches instead of graph replays when PYQSM_NO_GRAPH is set. The library no longer
-// looks at the profiler's environment: tools/profile_*.sh export PYQSM_NO_GRAPH=1 themselves
-// where a profile is meant to show plain launches, and say so next to the profile.
+// Plain launches instead of graph replays when PYQSM_NO_GRAPH is set. The library never looks
+// at the profiler's environment, and the profile scripts (tools/profile_r0*.sh) keep graphs ON:
+// what they measure is the shipped path. PYQSM_NO_GRAPH=1 is an explicit switch for whoever
+// wants a profile of plain launches.
 static bool graphs_enabled() { return !getenv("PYQSM_NO_GRAPH"); }
 
 // The multigrid-CG bursts are plain launches unless PYQSM_AMG_GRAPH is set: their graphs hold

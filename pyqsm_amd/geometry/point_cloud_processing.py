@@ -36,18 +36,20 @@ def _select(pcd, pts, idx):
 
 def cluster_plus(pcd, eps=config["trunk"]["cluster_eps"], min_points=config["trunk"]["cluster_nn"],
                  draw_result=True, color_clusters=True, from_points=True, return_pcds=True,
-                 ransac=False, device: int = 0):
+                 ransac=False, device: int = 0, radius_inclusive: bool = True):
     """point_cloud_processing.py:169-203. ``from_points=True`` (the default) means
     ``pcd`` is an array of points. Returns the list of sub-clouds, one per label in
     ascending label order (noise -1 first when present), or ``{label: indices}``
     when ``return_pcds`` is false. ``draw_result`` / ``color_clusters`` are accepted
-    and ignored (no GUI); ``ransac=True`` (Open3D plane segmentation) is out of scope."""
+    and ignored (no GUI); ``ransac=True`` (Open3D plane segmentation) is out of scope.
+    ``radius_inclusive=False`` switches the neighbourhood to d < eps — Open3D's compare if
+    nanoflann's radius search is strict (unverifiable here: parity unpinned, default inclusive)."""
     if ransac:
         raise NotImplementedError("plane segmentation (ransac=True) is not part of the HIP hot path")
     pts = as_points(pcd)
     if from_points:
         pcd = PointCloud(pts)
-    labels, _ = hip.dbscan(pts, eps, min_points, device=device)
+    labels, _ = hip.dbscan(pts, eps, min_points, device=device, radius_inclusive=radius_inclusive)
     unique_lbs, counts = np.unique(labels, return_counts=True)
     log.info(f"point cloud has {counts} clusters")
     label_to_cluster = {ulabel: np.where(labels == ulabel)[0] for ulabel in unique_lbs}
@@ -58,11 +60,11 @@ def cluster_plus(pcd, eps=config["trunk"]["cluster_eps"], min_points=config["tru
 
 def cluster_and_get_largest(pcd, eps=config["trunk"]["cluster_eps"],
                             min_points=config["trunk"]["cluster_nn"], draw_clusters=False,
-                            device: int = 0):
+                            device: int = 0, radius_inclusive: bool = True):
     """point_cloud_processing.py:205-218: the sub-cloud of the most populous label
     (noise counts as a label, as in the reference)."""
     pts = as_points(pcd)
-    labels, _ = hip.dbscan(pts, eps, min_points, device=device)
+    labels, _ = hip.dbscan(pts, eps, min_points, device=device, radius_inclusive=radius_inclusive)
     log.info(f"point cloud has {labels.max() + 1 if len(labels) else 0} clusters")
     if len(labels) == 0:
         return _select(pcd, pts, np.zeros(0, dtype=np.int64))

@@ -318,6 +318,25 @@ def _pack_groups(sizes, group_points):
     return groups
 
 
+def _lattice_offsets(pts):
+    """Translation of every cloud of a group to its own node of a coarse xy lattice, box centre on
+    the node. The Laplacian of the stacked clouds is block diagonal only if every point finds its
+    k nearest neighbours inside its own cloud: the GAP between neighbouring boxes (pitch minus the
+    largest extent along that axis) is therefore wider than the largest box DIAGONAL — no point
+    of a cloud with more than k points can then be nearer to a foreign point than to all of its
+    own (round 2 used 2 x extent + 1, a gap of extent + 1 against a diagonal of up to sqrt(3) x
+    extent; the library checks the outcome either way: k_check_segments). Translation changes
+    fp64 results only by the rounding of the shifted coordinates (~1e-16 x pitch / spacing)."""
+    S = len(pts)
+    ext = np.array([p.max(0) - p.min(0) for p in pts])
+    diag = float(np.sqrt((ext ** 2).sum(1)).max())
+    pitch_x = float(ext[:, 0].max()) + diag + 1.0
+    pitch_y = float(ext[:, 1].max()) + diag + 1.0
+    cols = int(np.ceil(np.sqrt(S)))
+    offs = np.array([[(j % cols) * pitch_x, (j // cols) * pitch_y, 0.0] for j in range(S)])
+    return offs - np.array([0.5 * (p.max(0) + p.min(0)) for p in pts])
+
+
 def _contract_group_native(clouds, moll, n_neighbors, max_iter, termination_ratio, contraction_factor,
                            attraction_factor, max_contraction, max_attraction, device):
     """:func:`_contract_group` inside the library: one ``pyqsm_extract_skeleton`` call with the
@@ -326,11 +345,7 @@ def _contract_group_native(clouds, moll, n_neighbors, max_iter, termination_rati
     pts = [np.array(as_points(c), dtype=np.float64) for c in clouds]
     sizes = np.array([len(p) for p in pts])
     start = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
-    ext = max(float((p.max(0) - p.min(0)).max()) for p in pts)
-    pitch = 2.0 * ext + 1.0
-    cols = int(np.ceil(np.sqrt(S)))
-    offs = np.array([[(j % cols) * pitch, (j // cols) * pitch, 0.0] for j in range(S)])
-    offs -= np.array([0.5 * (p.max(0) + p.min(0)) for p in pts])
+    offs = _lattice_offsets(pts)
     bounds = [oriented_bounds(p, device=device) for p in pts]
     lo = np.array([b[0] + o for b, o in zip(bounds, offs)])
     hi = np.array([b[1] + o for b, o in zip(bounds, offs)])
@@ -364,13 +379,7 @@ def _contract_group(clouds, moll, n_neighbors, max_iter, termination_ratio, cont
     sizes = np.array([len(p) for p in pts])
     seg = np.repeat(np.arange(S), sizes)
     start = np.concatenate([[0], np.cumsum(sizes)])
-    # lattice pitch: the largest extent plus a margin; translation changes fp64 results only by
-    # the rounding of the shifted coordinates (~1e-16 x pitch / point spacing)
-    ext = max(float((p.max(0) - p.min(0)).max()) for p in pts)
-    pitch = 2.0 * ext + 1.0
-    cols = int(np.ceil(np.sqrt(S)))
-    offs = np.array([[(j % cols) * pitch, (j // cols) * pitch, 0.0] for j in range(S)])
-    offs -= np.array([0.5 * (p.max(0) + p.min(0)) for p in pts])
+    offs = _lattice_offsets(pts)
     bounds = [oriented_bounds(p, device=device) for p in pts]           # :240-241, per cloud
     lo = np.concatenate([np.tile(b[0] + o, (n, 1)) for b, o, n in zip(bounds, offs, sizes)])
     hi = np.concatenate([np.tile(b[1] + o, (n, 1)) for b, o, n in zip(bounds, offs, sizes)])
@@ -447,13 +456,26 @@ def extract_skeleton_batch(pcds, moll=_SK["moll"], n_neighbors=_SK["n_neighbors"
     from concurrent.futures import ThreadPoolExecutor
     clouds = list(pcds)
     sizes = [len(as_points(c)) for c in clouds]
-    groups = _pack_groups(sizes, int(group_points))
+    # A cloud with too few points to have n_neighbors neighbours of its own (the small clusters of
+    # qsm_generation.py:182-316) cannot share a system with others — its missing neighbours would
+    # come from the next cloud. Below 2 k + 1 points it takes the single-cloud call, which handles
+    # n <= k.
+    small = [j for j, n in enumerate(sizes) if n < 2 * int(n_neighbors) + 1]
+    big = [j for j in range(len(clouds)) if sizes[j] >= 2 * int(n_neighbors) + 1]
+    groups = [[big[q] for q in g] for g in _pack_groups([sizes[j] for j in big], int(group_points))]
+    groups += [[j] for j in small]
     args = (moll, n_neighbors, max_iter, termination_ratio, contraction_factor, attraction_factor,
             max_contraction, max_attraction, device)
 
     fn = _contract_group_native if engine == "native" else _contract_group
 
     def run(g):
+        if len(g) == 1 and sizes[g[0]] < 2 * int(n_neighbors) + 1:
+            return g, [extract_skeleton(clouds[g[0]], moll=moll, n_neighbors=n_neighbors, max_iter=max_iter,
+                                        termination_ratio=termination_ratio, contraction_factor=contraction_factor,
+                                        attraction_factor=attraction_factor, max_contraction=max_contraction,
+                                        max_attraction=max_attraction, device=device,
+                                        engine="native" if engine == "native" else "python")]
         return g, fn([clouds[j] for j in g], *args)
 
     results = [None] * len(clouds)

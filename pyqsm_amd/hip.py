@@ -204,25 +204,27 @@ def cast_rays_dev(mesh: DeviceMesh, rays_ptr: int, n_rays: int, t_hit_ptr: int, 
 
 # ---------------------------------------------------------------- DBSCAN / kNN
 
-def dbscan(points, eps: float, min_pts: int, device: int = 0):
-    """labels int64 [n] (-1 = noise), core mask bool [n]."""
+def dbscan(points, eps: float, min_pts: int, device: int = 0, radius_inclusive: bool = True):
+    """labels int64 [n] (-1 = noise), core mask bool [n]. ``radius_inclusive=False``: the strict
+    neighbourhood d2 < eps^2 (``pyqsm_dbscan_ex``) instead of scikit-learn's d2 <= eps^2."""
     pts = _points(points)
     n = pts.shape[0]
     labels = np.empty(n, dtype=np.int64)
     core = np.zeros(n, dtype=np.uint8)
-    check(_lib.load().pyqsm_dbscan(_p(pts), n, float(eps), int(min_pts), _p(labels), _p(core),
-                                   int(device)))
+    check(_lib.load().pyqsm_dbscan_ex(_p(pts), n, float(eps), int(min_pts), int(bool(radius_inclusive)),
+                                      _p(labels), _p(core), int(device)))
     return labels, core.astype(bool)
 
 
 def dbscan_dev(xyz_ptr: int, n: int, eps: float, min_pts: int, labels_ptr: int,
-               core_ptr: int | None = None, device: int = 0, want_count: bool = False):
+               core_ptr: int | None = None, device: int = 0, want_count: bool = False,
+               radius_inclusive: bool = True):
     """Asynchronous clustering of an HBM-resident cloud; returns the cluster count
     when `want_count` (that read-back synchronises)."""
     cnt = i64(0)
-    check(_lib.load().pyqsm_dbscan_dev(xyz_ptr, int(n), float(eps), int(min_pts), labels_ptr,
-                                       core_ptr, ctypes.byref(cnt) if want_count else None,
-                                       int(device)))
+    check(_lib.load().pyqsm_dbscan_dev_ex(xyz_ptr, int(n), float(eps), int(min_pts),
+                                          int(bool(radius_inclusive)), labels_ptr, core_ptr,
+                                          ctypes.byref(cnt) if want_count else None, int(device)))
     return int(cnt.value) if want_count else None
 
 

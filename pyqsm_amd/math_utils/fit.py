@@ -117,7 +117,10 @@ def draw_samples(n_points: int, iterations: int, seed=None, method: str = "numpy
     distribution of pyransac3d's ``random.sample(range(n), 3)`` per iteration (the reference is
     unseeded, so no particular stream is part of its behaviour). ``method="numpy"`` draws all rows
     at once (a per-row ``random.sample`` loop costs 3 ms per 1000 hypotheses, ten times the fit
-    itself on a stem slice); ``method="stdlib"`` is that loop, from a private ``random.Random``."""
+    itself on a stem slice); ``method="stdlib"`` is that loop, from a private ``random.Random``.
+    ``seed`` may be an int, a ``numpy.random.SeedSequence`` or a ``numpy.random.Generator`` (the
+    batch call hands every point set its own spawned stream). Since round 2 the default stream
+    is NumPy's, so a seed used with round 1's ``random.Random`` draws yields other fits."""
     if n_points < 3:
         raise ValueError("need at least three points to draw a hypothesis")
     if method == "stdlib":
@@ -126,7 +129,7 @@ def draw_samples(n_points: int, iterations: int, seed=None, method: str = "numpy
                         dtype=np.int64).reshape(-1, 3)
     if method != "numpy":
         raise ValueError("method must be 'numpy' or 'stdlib'")
-    rng = np.random.default_rng(seed)
+    rng = seed if isinstance(seed, np.random.Generator) else np.random.default_rng(seed)
     a = rng.integers(0, n_points, iterations)
     b = rng.integers(0, n_points - 1, iterations)
     b += b >= a                                          # uniform over the n-1 values other than a
@@ -212,7 +215,10 @@ def fit_shape_RANSAC_batch(pts_list, threshold=0.1, lower_bound=None, max_radius
 
     ``pts_list``: arrays [n_i,3] (clamped in place by a truthy ``lower_bound`` like the single
     call); ``lower_bound`` / ``max_radius``: one value or one per set; ``samples``: one int64
-    [H,3] array per set (same H), or None to draw ``max_iterations`` rows per set from ``seed``.
+    [H,3] array per set (same H), or None to draw ``max_iterations`` rows per set. The sets get
+    INDEPENDENT streams spawned from ``seed`` (``SeedSequence(seed).spawn(S)``: set q always gets
+    child q, whatever the other sets are) — one shared seed would hand sets of equal size the
+    same hypothesis triples and correlate their fits.
     Returns one 5-tuple of :func:`fit_shape_RANSAC` per set (``in_pcd`` is None: arrays in)."""
     S = len(pts_list)
 
@@ -223,13 +229,14 @@ def fit_shape_RANSAC_batch(pts_list, threshold=0.1, lower_bound=None, max_radius
     kept, fit, tri = [], [], []
     out = [_NO_FIT] * S
     srcs = []
+    streams = np.random.SeedSequence(seed).spawn(S) if samples is None else None
     for q in range(S):
         pts, fit_pts = _ransac_points(None, pts_list[q], lbs[q], shape)
         srcs.append(pts)
         if fit_pts is None:
             log.info(f"no no fit {shape} found")
             continue
-        rows = draw_samples(len(fit_pts), iters, seed) if samples is None else np.asarray(samples[q])
+        rows = draw_samples(len(fit_pts), iters, streams[q]) if samples is None else np.asarray(samples[q])
         kept.append(q)
         fit.append(fit_pts)
         tri.append(np.ascontiguousarray(rows, dtype=np.int64).reshape(-1, 3))

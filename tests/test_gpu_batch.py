@@ -91,3 +91,56 @@ def test_stacked_laplacian_is_the_block_diagonal_of_the_per_cloud_ones(gpu):
     # lengths, other flips)
     L1, _ = sk.point_cloud_laplacian(P, mollify_factor=1e-3, n_neighbors=20, device=gpu)
     assert L1.nnz != want.nnz or np.abs(L1.data - want.data).max() > 1e-9 * scale
+
+
+def test_small_and_sparse_clouds_beside_a_large_one(gpu):
+    """a cloud with <= n_neighbors points (the small clusters of
+    qsm_generation.py:182-316) must not borrow neighbours from the cloud next to it, and a very
+    sparse cloud (k-th own neighbour farther away than a cloud diameter of the others) must stay
+    its own block. The 10-point cloud takes the single-cloud call (which handles n <= k), so its
+    result IS that call's; the sparse one shares the group and must agree with its own loop."""
+    rng = np.random.default_rng(11)
+    big = synth.forest(6000, seed=7)
+    tiny = rng.normal(0, 0.05, (10, 3)) + [0.0, 0.0, 1.0]
+    sparse = rng.uniform(-6, 6, (60, 3)) * [1, 1, 0.3] + [0, 0, 3.0]     # 60 points over 12 m
+    clouds = [big, tiny, sparse]
+    kw = dict(max_iter=3, termination_ratio=0.0, contraction_factor=3, attraction_factor=3)
+    for engine in ("python", "native"):
+        batch = sk.extract_skeleton_batch(clouds, group_points=100_000, workers=2, engine=engine, **kw)
+        single = [sk.extract_skeleton(P, engine=engine, **kw) for P in clouds]
+        assert np.array_equal(batch[1][0].points, single[1][0].points)            # same call, same bits
+        for j in (0, 2):
+            assert len(batch[j][2]) == len(single[j][2]) == 3
+            scale = np.abs(clouds[j]).max()
+            assert np.abs(batch[j][2][0] - single[j][2][0]).max() <= 2e-7 * scale, (engine, j)
+            assert np.abs(batch[j][0].points - single[j][0].points).max() <= 1e-3 * scale, (engine, j)
+
+
+def test_stacked_laplacian_refuses_clouds_that_see_each_other(gpu):
+    """The device check behind the batch (k_check_segments): a segment with <= k points, or two
+    clouds closer than their own point spacing, make the call fail instead of building fans across
+    clouds; clouds laid out by the batch's own lattice pass."""
+    from pyqsm_amd import _lib
+    rng = np.random.default_rng(5)
+    big = synth.forest(5000, seed=3)
+    tiny = rng.normal(0, 0.05, (10, 3)) + [30.0, 0.0, 1.0]
+    P = np.concatenate([big, tiny])
+    with pytest.raises(_lib.PyQSMHipError, match="another cloud"):
+        sk.point_cloud_laplacian(P, mollify_factor=1e-5, n_neighbors=20, device=gpu,
+                                 seg_start=np.array([0, len(big), len(P)]))
+    other = synth.forest(5000, seed=4) + [0.05, 0.0, 0.0]                  # interleaved with `big`
+    P2 = np.concatenate([big, other])
+    with pytest.raises(_lib.PyQSMHipError, match="another cloud"):
+        sk.point_cloud_laplacian(P2, mollify_factor=1e-5, n_neighbors=20, device=gpu,
+                                 seg_start=np.array([0, len(big), len(P2)]))
+    sparse = rng.uniform(-6, 6, (60, 3)) * [1, 1, 0.3]
+    pts = [big, sparse]
+    offs = sk._lattice_offsets(pts)
+    P3 = np.concatenate([p + o for p, o in zip(pts, offs)])
+    L, M = sk.point_cloud_laplacian(P3, mollify_factor=1e-5, n_neighbors=20, device=gpu,
+                                    seg_start=np.array([0, len(big), len(P3)]))
+    coo = L.tocoo()
+    assert not np.any((coo.row < len(big)) != (coo.col < len(big)))         # block diagonal
+    # and the library is usable after the refusals
+    L1, _ = sk.point_cloud_laplacian(big, mollify_factor=1e-5, n_neighbors=20, device=gpu)
+    assert L1.shape == (5000, 5000)

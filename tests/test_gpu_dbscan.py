@@ -185,3 +185,37 @@ def test_randomised_differential(gpu):
         lab0, core0 = oracle.dbscan(P, eps, min_pts)
         assert np.array_equal(core, core0), (case, n, eps, min_pts)
         assert np.array_equal(lab, lab0), (case, n, eps, min_pts)
+
+
+def test_points_exactly_eps_apart_under_both_radius_rules(gpu):
+    """pyqsm_dbscan_ex: on a lattice whose spacing IS eps (0.5: d2 = 0.25 = eps*eps exactly in
+    fp64) the inclusive rule (scikit-learn's, the default) makes every point with six lattice
+    neighbours a core point at min_pts = 7 and the block one cluster; the strict rule (Open3D's
+    compare if nanoflann's is strict) leaves every point alone. Both against the oracle's two
+    forms, and the strict rule on an ordinary cloud where the boundary is never hit."""
+    g = np.arange(12) * 0.5
+    P = np.array(np.meshgrid(g, g, g, indexing="ij")).reshape(3, -1).T.copy()
+    rng = np.random.default_rng(1)
+    P = P[rng.permutation(len(P))]
+    lab, core = hip.dbscan(P, 0.5, 7, device=gpu)                          # inclusive
+    lab0, core0 = oracle.dbscan(P, 0.5, 7)
+    assert np.array_equal(lab, lab0) and np.array_equal(core, core0)
+    interior = np.all((P > 0) & (P < 5.5), axis=1)
+    assert np.array_equal(core, interior) and lab.max() == 0 and (lab == 0).all()
+    for min_pts in (7, 2, 1):
+        lab, core = hip.dbscan(P, 0.5, min_pts, device=gpu, radius_inclusive=False)
+        lab0, core0 = oracle.dbscan(P, 0.5, min_pts, radius_inclusive=False)
+        assert np.array_equal(lab, lab0) and np.array_equal(core, core0)
+        if min_pts > 1:
+            assert not core.any() and (lab == -1).all()                    # nobody within d < eps
+        else:
+            assert core.all() and np.array_equal(np.sort(lab), np.arange(len(P)))   # every point its own cluster
+    # a hair above the lattice spacing both rules see the six neighbours
+    eps = np.nextafter(0.5, 1.0)
+    a = hip.dbscan(P, eps, 7, device=gpu, radius_inclusive=False)
+    b = hip.dbscan(P, eps, 7, device=gpu)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], interior)
+    Q = synth.forest(30_000, seed=9)
+    s_lab, s_core = hip.dbscan(Q, 0.1, 10, device=gpu, radius_inclusive=False)
+    o_lab, o_core = oracle.dbscan(Q, 0.1, 10, radius_inclusive=False)
+    assert np.array_equal(s_lab, o_lab) and np.array_equal(s_core, o_core)

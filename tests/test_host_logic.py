@@ -335,3 +335,35 @@ def test_unique_rows_mm_equals_numpy_row_unique():
         got = _unique_rows_mm(r)
         want = np.unique(r, axis=0)
         assert got.shape == want.shape and np.array_equal(got, want), scale
+
+
+def test_batch_ransac_gives_every_set_its_own_stream(monkeypatch):
+    """fit_shape_RANSAC_batch(seed=...) must not hand sets of equal size the same hypothesis
+    triples: set q draws from SeedSequence(seed).spawn(S)[q]. The GPU call is
+    replaced by a recorder — what is under test is what the wrapper sends to it."""
+    from pyqsm_amd.math_utils import fit
+    sent = {}
+
+    def recorder(stacked, seg, tri, shape, threshold, device=0):
+        sent["tri"], sent["seg"] = np.array(tri), np.array(seg)
+        S = len(seg) - 1
+        return (np.zeros((S, 3)), np.tile([0.0, 0.0, 1.0], (S, 1)), np.ones(S),
+                [np.arange(3, dtype=np.int64)] * S, np.zeros(S, dtype=np.int64))
+
+    monkeypatch.setattr(fit.hip, "ransac_batch", recorder)
+    rng = np.random.default_rng(0)
+    sets = [rng.normal(size=(500, 3)) for _ in range(4)]                 # equal sizes on purpose
+    fit.fit_shape_RANSAC_batch(sets, shape="circle", seed=2, max_iterations=200)
+    tri = sent["tri"]
+    assert tri.shape == (4, 200, 3)
+    for a in range(4):
+        assert np.all(tri[a] >= 0) and np.all(tri[a] < 500)
+        for b in range(a + 1, 4):
+            assert not np.array_equal(tri[a], tri[b])
+    first = tri.copy()
+    fit.fit_shape_RANSAC_batch(sets, shape="circle", seed=2, max_iterations=200)
+    assert np.array_equal(sent["tri"], first)                            # seeded: repeatable
+    fit.fit_shape_RANSAC_batch(sets[:2], shape="circle", seed=2, max_iterations=200)
+    assert np.array_equal(sent["tri"], first[:2])                        # set q's stream is child q
+    fit.fit_shape_RANSAC_batch(sets, shape="circle", seed=3, max_iterations=200)
+    assert not np.array_equal(sent["tri"], first)
