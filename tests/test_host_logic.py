@@ -75,7 +75,7 @@ def test_signatures_match_the_reference():
         "contraction_factor", "attraction_factor", "max_contraction", "max_attraction",
         "step_wise_contraction_amplification", "cmag_save_file", "min_contraction"]
     assert names(cluster_plus) == ["pcd", "eps", "min_points", "draw_result", "color_clusters",
-                                   "from_points", "return_pcds", "ransac", "device"]
+                                   "from_points", "return_pcds", "ransac", "device", "radius_inclusive"]
     assert names(cast_rays)[:4] == ["tmesh", "surf_2d", "img", "pinhole_config"]
     sig = inspect.signature(fit_shape_RANSAC)
     assert sig.parameters["threshold"].default == 0.1 and sig.parameters["shape"].default == "circle"
