@@ -66,6 +66,8 @@ def parse():
                     help="contraction steps of the skeleton section (config 3: 20)")
     ap.add_argument("--no-skeleton", action="store_true")
     ap.add_argument("--no-ransac", action="store_true")
+    ap.add_argument("--no-config5", action="store_true",
+                    help="skip the whole-pipeline section (configs[4] at its stated sizes, ~15 s)")
     return ap.parse_args()
 
 
@@ -529,6 +531,28 @@ def main():
                       "us_per_sample": t_pruned / s_fps * 1e6,
                       "same_indices": bool(np.array_equal(picked, whole)), "dtype": "f64",
                       "note": "host buffers in and out; whole-cloud rounds move 32 B per point and sample"}
+
+    # ------------------------------------------------------------- config 5: the whole pipeline
+    if not args.no_config5 and not args.no_skeleton and world == 1:
+        # BASELINE.json configs[4] at its stated sizes on this one GPU: 5 M points -> DBSCAN -> 100 trees
+        # through extract_skeleton_batch (20 contractions each) -> every stem slice through
+        # fit_shape_RANSAC_batch (H = 1000) -> 5 sun angles x 10 M culled rays; the driver is
+        # examples/config5_pipeline.py (tests/test_gpu_config5.py::test_whole_pipeline_at_stated_sizes
+        # checks the same run stage by stage against the oracles)
+        from examples import config5_pipeline as c5
+        rec, _ = c5.run(scale=1.0, skeleton_iters=20, max_trees=100, engine="native")
+        out["config5"] = {
+            "workload": "5 M-point scan (100 trees) -> DBSCAN -> 100 x extract_skeleton (20 contractions, "
+                        "block-diagonal batches of 600 k points) -> RANSAC circles on every 0.5 m stem slice "
+                        "(H = 1000) -> 50 M sun rays (5 angles x 10 M) x 500 k triangles; one MI355X, host "
+                        "buffers in and out at every stage (PCIe included)",
+            "stage_s": {k: rec[k] for k in ("dbscan_s", "skeleton_s", "ransac_s", "rays_s")},
+            "total_s": rec["total_s"], "clusters": rec["clusters"], "trees_contracted": rec["skeleton_trees"],
+            "slices_fitted": rec["ransac_fits"], "slices": rec["ransac_slices"],
+            "median_stem_radius_m": rec["ransac_median_radius_m"],
+            "intercepted_fraction": rec["intercepted_fraction"],
+            "Mpoints_per_s_end_to_end": rec["points"] / rec["total_s"] / 1e6,
+            "ransac_thread_seconds": rec["ransac_thread_seconds"]}
 
     # ------------------------------------------------------------- CPU baseline (primary)
     if rank == 0 and world == 1 and not args.no_cpu:

@@ -123,6 +123,21 @@ def device_count() -> int:
     return int(load().pyqsm_device_count())
 
 
+def logical_device_count() -> int:
+    """What a multi-GPU driver may address: the visible GPUs, or — with PYQSM_MULTI_FAKE_RANKS=N
+    (csrc/multi.hip: N logical ranks on one device, how one-GPU boxes run the N > 1 code) — N."""
+    fake = os.environ.get("PYQSM_MULTI_FAKE_RANKS", "")
+    return int(fake) if fake.isdigit() and int(fake) > 0 else device_count()
+
+
+def physical_device(logical: int) -> int:
+    """The real device behind a logical device index (identity unless PYQSM_MULTI_FAKE_RANKS is set)."""
+    fake = os.environ.get("PYQSM_MULTI_FAKE_RANKS", "")
+    if fake.isdigit() and int(fake) > 0:
+        return int(logical) % max(1, device_count())
+    return int(logical)
+
+
 def require_gpu(device: int = 0) -> None:
     """Raise unless `device` is a usable GPU."""
     check(load().pyqsm_init(int(device)))

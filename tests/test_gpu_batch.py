@@ -110,7 +110,10 @@ def test_small_and_sparse_clouds_beside_a_large_one(gpu):
         single = [sk.extract_skeleton(P, engine=engine, **kw) for P in clouds]
         assert np.array_equal(batch[1][0].points, single[1][0].points)            # same call, same bits
         for j in (0, 2):
-            assert len(batch[j][2]) == len(single[j][2]) == 3
+            # (the 60-point cloud stops early on its own — its third solve returns the warm start
+            # unchanged, skeletonize.py:287-289 — while in a group the shared CG scalars leave it
+            # shifts of 1e-9: one more recorded step, the same cloud)
+            assert len(single[j][2]) <= len(batch[j][2]) <= 3 and len(batch[0][2]) == 3
             scale = np.abs(clouds[j]).max()
             assert np.abs(batch[j][2][0] - single[j][2][0]).max() <= 2e-7 * scale, (engine, j)
             assert np.abs(batch[j][0].points - single[j][0].points).max() <= 1e-3 * scale, (engine, j)

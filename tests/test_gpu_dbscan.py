@@ -201,7 +201,8 @@ def test_points_exactly_eps_apart_under_both_radius_rules(gpu):
     lab0, core0 = oracle.dbscan(P, 0.5, 7)
     assert np.array_equal(lab, lab0) and np.array_equal(core, core0)
     interior = np.all((P > 0) & (P < 5.5), axis=1)
-    assert np.array_equal(core, interior) and lab.max() == 0 and (lab == 0).all()
+    assert np.array_equal(core, interior) and lab.max() == 0 and (lab[core] == 0).all()
+    assert (lab == -1).sum() == 128                            # edges and corners of the block: no core neighbour
     for min_pts in (7, 2, 1):
         lab, core = hip.dbscan(P, 0.5, min_pts, device=gpu, radius_inclusive=False)
         lab0, core0 = oracle.dbscan(P, 0.5, min_pts, radius_inclusive=False)
