@@ -738,6 +738,273 @@ __global__ __launch_bounds__(256) void k_order_big(const int32_t* __restrict__ b
   }
 }
 
+// ---- the same outputs without scattered global atomics and without a pass over the directory ----
+// Round 2's binning above costs one returning atomic per point at 64 different lines per wave
+// instruction (the chip's scattered-atomic rate: 51 us per million points), a memset and a
+// three-phase scan of the dense directory (16 M cells: 65 us), a 32-byte record scattered and read
+// back (20 + 48 us). This version splits the counting sort in two levels so that every atomic
+// is either in LDS or lands, 64 lanes wide, on 64 CONSECUTIVE counters (4 memory requests instead of
+// 64), and the directory is written exactly once, by the blocks that sort:
+//   A1  k_bk_hist     cell and octant of every point; per block an LDS histogram over the BUCKETS
+//                     (a bucket = kBkCells consecutive cell ids), flushed with one atomic per
+//                     non-empty (block, bucket), lanes on consecutive buckets
+//       k_bk_scan     exclusive scan of the <= 8192 bucket totals (one block)
+//   A2  k_bk_scatter  the same LDS histogram again, this time returning the rank inside the block;
+//                     a block reserves its share of every bucket with one returning atomic
+//                     (same shape) and writes the 32-byte records bucket by bucket
+//   B   k_bk_sort     one block per bucket, everything in LDS: a count per cell (arrival rank) and
+//                     eight 8-bit counts per cell packed in a u64 (rank inside the octant), a block
+//                     scan of the bucket's cell counts -> the bucket's 8192 directory entries,
+//                     written once and coalesced; every point then goes straight to its final,
+//                     octant-ordered place. Cells with more than 255 points (a packed count could
+//                     overflow) are listed for k_order_big exactly as before.
+// Same arrays as build_grid_octants leaves (the order inside a sub-cell is the arrival order of
+// atomics in both versions, and nothing downstream depends on it).
+static constexpr int kBkBits = 13;
+static constexpr int kBkCells = 1 << kBkBits;   // cells per bucket: 64 KB of packed counts in LDS
+static constexpr int kBkMax = 8192;             // buckets (LDS histogram of the A passes: 32 KB)
+static constexpr int kBkPts = 2048;             // points per block of the A passes
+static constexpr int kBkBig = 255;              // cells above this go through k_order_big
+
+template <bool MAPPED>
+__global__ __launch_bounds__(256) void k_bk_hist(const double* __restrict__ xyz, int64_t n, GridParams g,
+                                                 int rx, int ry, int rz, AxisMap am, int nbk,
+                                                 int32_t* __restrict__ key_tmp,
+                                                 int32_t* __restrict__ tot) {
+  extern __shared__ __attribute__((aligned(16))) int32_t h[];
+  for (int b = threadIdx.x; b < nbk; b += 256) h[b] = 0;
+  __syncthreads();
+  const int64_t base = int64_t(blockIdx.x) * kBkPts;
+#pragma unroll
+  for (int k = 0; k < kBkPts / 256; ++k) {
+    const int64_t i = base + k * 256 + threadIdx.x;
+    if (i < n) {
+      const RawCell r = raw_cell(g, rx, ry, rz, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
+      const int cx = MAPPED ? am.x[r.cx] : r.cx + 1, cy = MAPPED ? am.y[r.cy] : r.cy + 1,
+                cz = MAPPED ? am.z[r.cz] : r.cz + 1;
+      const int c = (cz * g.ny + cy) * g.nx + cx;
+      key_tmp[i] = (c << 3) | r.oct;
+      atomicAdd(&h[c >> kBkBits], 1);  // LDS
+    }
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < nbk; b += 256) {
+    const int v = h[b];
+    if (v) atomicAdd(&tot[b], v);  // lanes on consecutive counters: 4 requests per wave instruction
+  }
+}
+
+// one block: bstart[b] = points in buckets before b (bstart[nbk] = n), cursor = a copy to reserve from
+__global__ __launch_bounds__(1024) void k_bk_scan(int nbk, const int32_t* __restrict__ tot,
+                                                  int32_t* __restrict__ bstart,
+                                                  int32_t* __restrict__ cursor) {
+  __shared__ int32_t wsum[16];
+  const int per = (nbk + 1023) / 1024;  // <= 8
+  const int b0 = threadIdx.x * per;
+  int32_t v[8], s = 0;
+  for (int k = 0; k < per; ++k) {
+    v[k] = b0 + k < nbk ? tot[b0 + k] : 0;
+    s += v[k];
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int32_t incl = s;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int32_t t = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += t;
+  }
+  if (lane == 63) wsum[w] = incl;
+  __syncthreads();
+  int32_t run = incl - s;
+  for (int q = 0; q < w; ++q) run += wsum[q];
+  for (int k = 0; k < per; ++k) {
+    if (b0 + k < nbk) {
+      bstart[b0 + k] = run;
+      cursor[b0 + k] = run;
+    }
+    run += v[k];
+  }
+  if (threadIdx.x == 1023) bstart[nbk] = run;
+}
+
+__global__ __launch_bounds__(256) void k_bk_scatter(const double* __restrict__ xyz, int64_t n, int nbk,
+                                                    const int32_t* __restrict__ key_tmp,
+                                                    int32_t* __restrict__ cursor,
+                                                    PointRec* __restrict__ bucketed) {
+  extern __shared__ __attribute__((aligned(16))) int32_t h[];
+  for (int b = threadIdx.x; b < nbk; b += 256) h[b] = 0;
+  __syncthreads();
+  const int64_t base = int64_t(blockIdx.x) * kBkPts;
+  int key[kBkPts / 256], lr[kBkPts / 256];
+#pragma unroll
+  for (int k = 0; k < kBkPts / 256; ++k) {
+    const int64_t i = base + k * 256 + threadIdx.x;
+    key[k] = i < n ? key_tmp[i] : -1;
+    lr[k] = key[k] >= 0 ? atomicAdd(&h[key[k] >> (3 + kBkBits)], 1) : 0;  // rank inside this block's share
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < nbk; b += 256) {
+    const int v = h[b];
+    if (v) h[b] = atomicAdd(&cursor[b], v);  // this block's share of the bucket starts here
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kBkPts / 256; ++k) {
+    if (key[k] < 0) continue;
+    const int64_t i = base + k * 256 + threadIdx.x;
+    PointRec r;
+    r.x = xyz[3 * i];
+    r.y = xyz[3 * i + 1];
+    r.z = xyz[3 * i + 2];
+    r.idx = int(i);
+    r.key = key[k];
+    bucketed[h[key[k] >> (3 + kBkBits)] + lr[k]] = r;
+  }
+}
+
+// sum of the bytes of x below byte o (eight 8-bit counts packed in a u64)
+__device__ __forceinline__ int bytes_below(unsigned long long x, int o) {
+  x &= (1ull << (8 * o)) - 1ull;
+  x = (x & 0x00FF00FF00FF00FFull) + ((x >> 8) & 0x00FF00FF00FF00FFull);
+  x = (x & 0x0000FFFF0000FFFFull) + ((x >> 16) & 0x0000FFFF0000FFFFull);
+  return int((x + (x >> 32)) & 0xFFFFull);
+}
+
+struct BkLds {
+  unsigned long long oct[kBkCells];  // eight 8-bit counts per cell
+  int32_t cnt[kBkCells];             // points per cell, then (in place) the cell's offset in the bucket
+  uint32_t big[kBkCells / 32];       // cells with more than kBkBig points
+  int32_t wsum[16];
+};
+
+__global__ __launch_bounds__(1024) void k_bk_sort(int64_t ncell1 /*directory entries: ncell + 1*/,
+                                                  const int32_t* __restrict__ bstart,
+                                                  const PointRec* __restrict__ bucketed,
+                                                  int32_t* __restrict__ rank_tmp,
+                                                  uint8_t* __restrict__ oct_rank,
+                                                  int32_t* __restrict__ start,
+                                                  int32_t* __restrict__ order,
+                                                  int32_t* __restrict__ cell_of,
+                                                  int32_t* __restrict__ sub_of,
+                                                  double* __restrict__ sx, double* __restrict__ sy,
+                                                  double* __restrict__ sz,
+                                                  int32_t* __restrict__ sub_cnt,
+                                                  int32_t* __restrict__ sub_beg,
+                                                  int4* __restrict__ rec, PointRec* __restrict__ keyed,
+                                                  int32_t* __restrict__ big_list,
+                                                  int32_t* __restrict__ big_cnt) {
+  __shared__ BkLds L;
+  const int bk = blockIdx.x, t = threadIdx.x;
+  const int s = bstart[bk], e = bstart[bk + 1];
+  const int64_t c0 = int64_t(bk) << kBkBits;  // first cell (directory entry) of the bucket
+  if (s == e) {  // nothing in the bucket: its directory entries all say "the next point is s"
+#pragma unroll
+    for (int k = 0; k < kBkCells / 1024; k += 4) {
+      const int64_t cidx = c0 + int64_t(k / 4 * 1024 + t) * 4;
+      if (cidx + 3 < ncell1) {
+        *reinterpret_cast<int4*>(start + cidx) = make_int4(s, s, s, s);
+      } else {
+        for (int u = 0; u < 4; ++u)
+          if (cidx + u < ncell1) start[cidx + u] = s;
+      }
+    }
+    return;
+  }
+  for (int q = t; q < kBkCells; q += 1024) {
+    L.oct[q] = 0ull;
+    L.cnt[q] = 0;
+  }
+  if (t < kBkCells / 32) L.big[t] = 0u;
+  __syncthreads();
+  // sweep 1: arrival rank in the cell and in the octant
+  for (int j = s + t; j < e; j += 1024) {
+    const int key = bucketed[j].key;
+    const int cl = (key >> 3) & (kBkCells - 1), o = key & 7;
+    rank_tmp[j] = atomicAdd(&L.cnt[cl], 1);
+    const unsigned long long old = atomicAdd(&L.oct[cl], 1ull << (8 * o));
+    oct_rank[j] = uint8_t(old >> (8 * o));  // meaningful only in cells of at most kBkBig points
+  }
+  __syncthreads();
+  // the bucket's cells: thread t owns eight consecutive ones
+  int32_t v[8], tot = 0;
+  {
+    const int4 a = *reinterpret_cast<const int4*>(&L.cnt[8 * t]);
+    const int4 b = *reinterpret_cast<const int4*>(&L.cnt[8 * t + 4]);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+    v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tot += v[k];
+  }
+  const int lane = t & 63, w = t >> 6;
+  int32_t incl = tot;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int32_t u = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += u;
+  }
+  if (lane == 63) L.wsum[w] = incl;
+  __syncthreads();
+  int32_t run = incl - tot;
+  for (int q = 0; q < w; ++q) run += L.wsum[q];
+  int32_t pre[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    pre[k] = run;
+    run += v[k];
+  }
+  {
+    const int64_t cidx = c0 + 8 * t;
+    if (cidx + 7 < ncell1) {
+      *reinterpret_cast<int4*>(start + cidx) = make_int4(s + pre[0], s + pre[1], s + pre[2], s + pre[3]);
+      *reinterpret_cast<int4*>(start + cidx + 4) = make_int4(s + pre[4], s + pre[5], s + pre[6], s + pre[7]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (cidx + k < ncell1) start[cidx + k] = s + pre[k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int cl = 8 * t + k;
+    L.cnt[cl] = pre[k];
+    if (v[k] == 0) continue;
+    const int b = s + pre[k];  // the cell's first sorted position: identifies its sub-cells
+    if (v[k] > kBkBig) {
+      atomicOr(&L.big[cl >> 5], 1u << (cl & 31));
+      big_list[atomicAdd(big_cnt, 1)] = int(c0) + cl;  // rare; k_order_big writes the cell's records
+      continue;
+    }
+    const unsigned long long c64 = L.oct[cl];
+    int r2 = b;
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+      const int cnt = int((c64 >> (8 * o)) & 255ull);
+      sub_beg[size_t(b) * 8 + o] = r2;
+      sub_cnt[size_t(b) * 8 + o] = cnt;
+      rec[size_t(b) * 8 + o] = make_int4(r2, cnt, -1, 0);
+      r2 += cnt;
+    }
+  }
+  __syncthreads();
+  // sweep 2: every point to its final place (big cells: to the cell's run of `keyed`, in arrival order)
+  for (int j = s + t; j < e; j += 1024) {
+    const PointRec me = bucketed[j];
+    const int cl = (me.key >> 3) & (kBkCells - 1), o = me.key & 7;
+    const int b = s + L.cnt[cl];
+    if ((L.big[cl >> 5] >> (cl & 31)) & 1u) {
+      keyed[b + rank_tmp[j]] = me;
+      continue;
+    }
+    const int f = b + bytes_below(L.oct[cl], o) + int(oct_rank[j]);
+    order[f] = me.idx;
+    cell_of[f] = me.key >> 3;
+    sub_of[f] = b * 8 + o;
+    sx[f] = me.x;
+    sy[f] = me.y;
+    sz[f] = me.z;
+  }
+}
+
 int build_grid_octants(Ctx* c, const double* xyz, int64_t n, double min_cell, int64_t max_cells,
                        DevGrid* g, SubCells* sub) {
   if (n <= 0) return fail(PYQSM_EINVAL, "build_grid_octants: empty cloud");
@@ -824,9 +1091,44 @@ int build_grid_octants(Ctx* c, const double* xyz, int64_t n, double min_cell, in
   PQ_TRY(c->arena.get(size_t(n) * 8, &sub->rec));
   PQ_TRY(c->arena.get(size_t(n) / kBigCell + 2, &big_list));
   PQ_TRY(c->arena.get(1, &big_cnt));
-  PQ_HIP(hipMemsetAsync(g->start, 0, (size_t(g->ncell) + 1) * 4, c->stream));
   PQ_HIP(hipMemsetAsync(big_cnt, 0, 4, c->stream));
   GridParams gp{g->minx, g->miny, g->minz, g->inv_cell, g->nx, g->ny, g->nz};
+  // Two-level counting sort (k_bk_*): no scattered global atomics, the directory written once.
+  // PYQSM_DBSCAN_BIN=atomic keeps round 2's one-atomic-per-point path (A/B comparisons); grids of
+  // more than kBkMax buckets (2^26 cells) keep it too.
+  const int64_t nbk = (g->ncell + 1 + kBkCells - 1) >> kBkBits;
+  const char* bin_env = getenv("PYQSM_DBSCAN_BIN");
+  if (nbk <= kBkMax && !(bin_env && !strcmp(bin_env, "atomic"))) {
+    int32_t *tot, *bstart, *cursor;
+    uint8_t* oct_rank;
+    PointRec* bucketed;
+    PQ_TRY(c->arena.get(size_t(nbk), &tot));
+    PQ_TRY(c->arena.get(size_t(nbk) + 1, &bstart));
+    PQ_TRY(c->arena.get(size_t(nbk), &cursor));
+    PQ_TRY(c->arena.get(size_t(n), &oct_rank));
+    PQ_TRY(c->arena.get(size_t(n), &bucketed));
+    PQ_HIP(hipMemsetAsync(tot, 0, size_t(nbk) * 4, c->stream));
+    const dim3 ga(ceil_div(n, kBkPts));
+    const size_t lds = size_t(nbk) * 4;
+    if (mapped)
+      hipLaunchKernelGGL(k_bk_hist<true>, ga, blk, lds, c->stream, xyz, n, gp, raw[0], raw[1], raw[2], am,
+                         int(nbk), cell_tmp, tot);
+    else
+      hipLaunchKernelGGL(k_bk_hist<false>, ga, blk, lds, c->stream, xyz, n, gp, raw[0], raw[1], raw[2], am,
+                         int(nbk), cell_tmp, tot);
+    hipLaunchKernelGGL(k_bk_scan, dim3(1), dim3(1024), 0, c->stream, int(nbk), tot, bstart, cursor);
+    hipLaunchKernelGGL(k_bk_scatter, ga, blk, lds, c->stream, xyz, n, int(nbk), cell_tmp, cursor, bucketed);
+    hipLaunchKernelGGL(k_bk_sort, dim3(unsigned(nbk)), dim3(1024), 0, c->stream, g->ncell + 1, bstart, bucketed,
+                       rank_tmp, oct_rank, g->start, g->order, g->cell_of, sub->sub_of, g->sx, g->sy, g->sz,
+                       sub->sub_cnt, sub->sub_beg, sub->rec, keyed, big_list, big_cnt);
+    PQ_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_order_big, dim3(unsigned(std::min<int64_t>(n / kBigCell + 1, 2048))), blk, 0,
+                       c->stream, big_list, big_cnt, g->start, keyed, g->order, g->cell_of, sub->sub_of,
+                       g->sx, g->sy, g->sz, sub->sub_cnt, sub->sub_beg, sub->rec);
+    PQ_HIP(hipGetLastError());
+    return 0;
+  }
+  PQ_HIP(hipMemsetAsync(g->start, 0, (size_t(g->ncell) + 1) * 4, c->stream));
   if (mapped)
     hipLaunchKernelGGL(k_cell_count_oct<true>, grid, blk, 0, c->stream, xyz, n, gp, raw[0], raw[1], raw[2],
                        am, g->start, cell_tmp, rank_tmp);
