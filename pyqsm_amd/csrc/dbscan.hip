@@ -67,12 +67,10 @@ static constexpr int kMaxChunks = 6;
 // centre, same-z rows, same-y rows, corners (compile-time: the run bounds stay in SGPRs)
 __device__ constexpr int kRunOrder[9] = {4, 3, 5, 1, 7, 0, 2, 6, 8};
 
+template <class CO>
 __global__ __launch_bounds__(256) void k_core_tiled(int n, Stencil st, int ncell,
                                                     const int32_t* __restrict__ start,
-                                                    const int32_t* __restrict__ cell_of,
-                                                    const double* __restrict__ sx,
-                                                    const double* __restrict__ sy,
-                                                    const double* __restrict__ sz, double r2,
+                                                    const int32_t* __restrict__ cell_of, CO co, double r2,
                                                     int min_pts, uint8_t* __restrict__ core,
                                                     int32_t* __restrict__ rest,
                                                     int32_t* __restrict__ rest_cnt,
@@ -86,7 +84,8 @@ __global__ __launch_bounds__(256) void k_core_tiled(int n, Stencil st, int ncell
   if (p0 >= n) return;  // whole wave
   const int p = p0 + lane;
   const bool live = p < n;
-  const double x = live ? sx[p] : 0.0, y = live ? sy[p] : 0.0, z = live ? sz[p] : 0.0;
+  double x = 0.0, y = 0.0, z = 0.0;
+  if (live) co.get(p, x, y, z);
   const Tile t = wave_tile(p0, n, st, ncell, start, cell_of);
   int cnt = 0;  // (starting lanes of sub-cells with >= min_pts points as "decided" gained nothing)
   bool deferred = false;
@@ -113,11 +112,7 @@ __global__ __launch_bounds__(256) void k_core_tiled(int n, Stencil st, int ncell
           for (int base = qb; base < qe; base += 64) {
             const int q = base + lane;
             const int m = qe - base < 64 ? qe - base : 64;
-            if (q < qe) {
-              L.x[w][lane] = sx[q];
-              L.y[w][lane] = sy[q];
-              L.z[w][lane] = sz[q];
-            }
+            if (q < qe) co.get(q, L.x[w][lane], L.y[w][lane], L.z[w][lane]);
             __builtin_amdgcn_wave_barrier();
             staged += m;
             if (mine)
@@ -134,11 +129,7 @@ __global__ __launch_bounds__(256) void k_core_tiled(int n, Stencil st, int ncell
       for (int base = t.qb[r]; base < t.qe[r] && !deferred; base += 64) {
         const int q = base + lane;
         const int m = t.qe[r] - base < 64 ? t.qe[r] - base : 64;
-        if (q < t.qe[r]) {
-          L.x[w][lane] = sx[q];
-          L.y[w][lane] = sy[q];
-          L.z[w][lane] = sz[q];
-        }
+        if (q < t.qe[r]) co.get(q, L.x[w][lane], L.y[w][lane], L.z[w][lane]);
         __builtin_amdgcn_wave_barrier();
         staged += m;
 #pragma unroll 4
@@ -173,19 +164,18 @@ __global__ __launch_bounds__(256) void k_core_tiled(int n, Stencil st, int ncell
 // The stragglers of k_core_tiled, one WAVE each: 64 candidates of the stencil per step,
 // stop at min_pts. (One lane each was 0.13 ms per million points: a noise point walks
 // ~850 candidates one dependent load at a time.)
+template <class CO>
 __global__ __launch_bounds__(256) void k_core_rest(const int32_t* __restrict__ rest,
                                                    const int32_t* __restrict__ rest_cnt, Stencil st,
                                                    const int32_t* __restrict__ start,
-                                                   const int32_t* __restrict__ cell_of,
-                                                   const double* __restrict__ sx,
-                                                   const double* __restrict__ sy,
-                                                   const double* __restrict__ sz, double r2,
+                                                   const int32_t* __restrict__ cell_of, CO co, double r2,
                                                    int min_pts, uint8_t* __restrict__ core) {
   const int m = *rest_cnt;
   const int lane = threadIdx.x & 63;
   for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < m; i += gridDim.x * 4) {  // wave-uniform
     const int p = rest[i];
-    const double x = sx[p], y = sy[p], z = sz[p];
+    double x, y, z;
+    co.get(p, x, y, z);
     const int c = cell_of[p];
     int cnt = 0;
     for (int dz = -1; dz <= 1 && cnt < min_pts; ++dz)
@@ -194,7 +184,7 @@ __global__ __launch_bounds__(256) void k_core_rest(const int32_t* __restrict__ r
         const int qe = start[row + 2];
         for (int base = start[row - 1]; base < qe && cnt < min_pts; base += 64) {
           const int q = base + lane;
-          const bool hit = q < qe && sqdist(x, y, z, sx[q], sy[q], sz[q]) <= r2;
+          const bool hit = q < qe && co.d2(q, x, y, z) <= r2;
           cnt += __popcll(__ballot(hit));
         }
       }
@@ -282,8 +272,6 @@ __global__ __launch_bounds__(256) void k_union_init(int n, int* __restrict__ par
 // The first point of every sub-cell run finds the run's first core point (the sub-cell's
 // representative), hangs the other core points of the run under it and lists it.
 __global__ __launch_bounds__(1024) void k_sub_rep(int n, const int32_t* __restrict__ sub_of,
-                                                 const int32_t* __restrict__ sub_beg,
-                                                 const int32_t* __restrict__ sub_cnt,
                                                  const uint8_t* __restrict__ core,
                                                  const int32_t* __restrict__ order,
                                                  int* __restrict__ parent,
@@ -296,8 +284,9 @@ __global__ __launch_bounds__(1024) void k_sub_rep(int n, const int32_t* __restri
   int rep = -1, sid = 0, e = 0;
   if (p < n) {
     sid = sub_of[p];
-    if (sub_beg[sid] == p) {
-      e = p + sub_cnt[sid];
+    const int4 run = rec[sid];  // (first position, points, -, -) of the sub-cell
+    if (run.x == p) {
+      e = p + run.y;
       int mn = 0x7FFFFFFF;
       for (int q = p; q < e; ++q)
         if (core[q]) {
@@ -364,14 +353,11 @@ __global__ __launch_bounds__(256) void k_flatten_reps(const int4* __restrict__ l
 // no cycle, every sub-cell writes its own pointer only (plain store, no atomics, no
 // chasing), and what remains after compression is a few trees per cluster — one per
 // sub-cell without a connected smaller neighbour. One wave per sub-cell as below.
-template <int kSubPerWave>
+template <int kSubPerWave, class CO>
 __global__ __launch_bounds__(256) void k_hook_sub(const int4* __restrict__ list,
                                                   const int32_t* __restrict__ m_ptr, int nx,
                                                   int ny, const int32_t* __restrict__ start,
-                                                  const int4* __restrict__ rec,
-                                                  const double* __restrict__ sx,
-                                                  const double* __restrict__ sy,
-                                                  const double* __restrict__ sz, double r2,
+                                                  const int4* __restrict__ rec, CO co, double r2,
                                                   const uint8_t* __restrict__ core,
                                                   int* __restrict__ parent,
                                                   int32_t* __restrict__ nbr) {
@@ -439,7 +425,7 @@ __global__ __launch_bounds__(256) void k_hook_sub(const int4* __restrict__ list,
         bool hit = false;
         if (idx < pairs) {
           const int a = p + idx / nb, q = qb + idx % nb;
-          hit = core[a] && core[q] && sqdist(sx[a], sy[a], sz[a], sx[q], sy[q], sz[q]) <= r2;
+          hit = core[a] && core[q] && co.d2(a, q) <= r2;
         }
         found = __ballot(hit) != 0;
       }
@@ -460,15 +446,12 @@ __global__ __launch_bounds__(256) void k_hook_sub(const int4* __restrict__ list,
 // tests all |S1| x |S2| point pairs at once, 64 per step. (A lane per pair of sub-cells
 // running the pair loop itself was 3x slower: ~25 dependent iterations per lane, and a wave
 // lasts as long as its slowest lane.)
-template <int kSubPerWave>
+template <int kSubPerWave, class CO>
 __global__ __launch_bounds__(256) void k_union_sub(const int4* __restrict__ list,
                                                    const int32_t* __restrict__ m_ptr,
                                                    const int32_t* __restrict__ nbr,
                                                    const int32_t* __restrict__ sub_of,
-                                                   const int4* __restrict__ rec,
-                                                   const double* __restrict__ sx,
-                                                   const double* __restrict__ sy,
-                                                   const double* __restrict__ sz, double r2,
+                                                   const int4* __restrict__ rec, CO co, double r2,
                                                    const uint8_t* __restrict__ core, int* parent) {
   const int m = *m_ptr;
   const int s0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * kSubPerWave;
@@ -517,7 +500,7 @@ __global__ __launch_bounds__(256) void k_union_sub(const int4* __restrict__ list
         bool hit = false;
         if (idx < pairs) {
           const int a = p + idx / nb, q = qb + idx % nb;
-          hit = core[a] && core[q] && sqdist(sx[a], sy[a], sz[a], sx[q], sy[q], sz[q]) <= r2;
+          hit = core[a] && core[q] && co.d2(a, q) <= r2;
         }
         found = __ballot(hit) != 0;
       }
@@ -530,22 +513,21 @@ __global__ __launch_bounds__(256) void k_union_sub(const int4* __restrict__ list
 // When the cloud's extent would need more than 2^28 cells of edge eps, grid.hip doubles the
 // edge; a sub-cell is then wider than eps and says nothing about connectivity. Such clouds
 // take the per-point union-find of the first version (same results, ~3x slower union phase).
+template <class CO>
 __global__ __launch_bounds__(256) void k_union_points(int n, Stencil st,
                                                       const int32_t* __restrict__ start,
-                                                      const int32_t* __restrict__ cell_of,
-                                                      const double* __restrict__ sx,
-                                                      const double* __restrict__ sy,
-                                                      const double* __restrict__ sz, double r2,
+                                                      const int32_t* __restrict__ cell_of, CO co, double r2,
                                                       const uint8_t* __restrict__ core, int* parent) {
   int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= n || !core[p]) return;
-  const double x = sx[p], y = sy[p], z = sz[p];
+  double x, y, z;
+  co.get(p, x, y, z);
   const int c = cell_of[p];
   const volatile int* vparent = parent;
   int rp = find_root(parent, p);
   FOR_STENCIL(c, st, start, q, {
     // each unordered pair once; a plain read equal to p's root proves "same tree"
-    if (q < p && core[q] && sqdist(x, y, z, sx[q], sy[q], sz[q]) <= r2) {
+    if (q < p && core[q] && co.d2(q, x, y, z) <= r2) {
       if (vparent[q] != rp) {
         unite(parent, p, q);
         rp = find_root(parent, p);
@@ -665,13 +647,11 @@ __global__ __launch_bounds__(256) void k_labels(int n, const uint8_t* __restrict
 }
 
 // One WAVE per non-core point: smallest cluster number among its core neighbours, or -1.
+template <class CO>
 __global__ __launch_bounds__(256) void k_labels_border(const int32_t* __restrict__ rest,
                                                        const int32_t* __restrict__ rest_cnt,
                                                        Stencil st, const int32_t* __restrict__ start,
-                                                       const int32_t* __restrict__ cell_of,
-                                                       const double* __restrict__ sx,
-                                                       const double* __restrict__ sy,
-                                                       const double* __restrict__ sz, double r2,
+                                                       const int32_t* __restrict__ cell_of, CO co, double r2,
                                                        const uint8_t* __restrict__ core,
                                                        const int* __restrict__ parent,
                                                        const int* __restrict__ min_orig,
@@ -682,7 +662,8 @@ __global__ __launch_bounds__(256) void k_labels_border(const int32_t* __restrict
   const int lane = threadIdx.x & 63;
   for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < m; i += gridDim.x * 4) {  // wave-uniform
     const int p = rest[i];
-    const double x = sx[p], y = sy[p], z = sz[p];
+    double x, y, z;
+    co.get(p, x, y, z);
     const int c = cell_of[p];
     int best = kNoRoot;
     for (int dz = -1; dz <= 1; ++dz)
@@ -691,7 +672,7 @@ __global__ __launch_bounds__(256) void k_labels_border(const int32_t* __restrict
         const int qe = start[row + 2];
         for (int base = start[row - 1]; base < qe; base += 64) {
           const int q = base + lane;
-          if (q < qe && core[q] && sqdist(x, y, z, sx[q], sy[q], sz[q]) <= r2) {
+          if (q < qe && core[q] && co.d2(q, x, y, z) <= r2) {
             const int mo = min_orig[parent[q]];
             best = mo < best ? mo : best;
           }
@@ -727,6 +708,7 @@ static int dbscan_device(Ctx* c, const double* xyz, int64_t n, double eps, int32
       PQ_TRY(build_grid_octants(c, xyz, n, eps * (1.0 + 1.0 / 1048576.0), int64_t(1) << 28, &g, &sub));
     }
   }
+  if (c->prof >= 1) c->timers["dbscan_f32_records"].launches += g.p4 ? 1 : 0;  // which storage form ran
   // the sub-cell shortcuts need cells of edge eps (not doubled to fit the dense grid)
   const bool fine = g.cell <= eps * (1.0 + 1.0 / 524288.0);
   const int N = int(n);
@@ -762,8 +744,10 @@ static int dbscan_device(Ctx* c, const double* xyz, int64_t n, double eps, int32
     }
     {
       ProfScope pk(c, "k_core_tiled");
-      hipLaunchKernelGGL(k_core_tiled, grid, block, 0, c->stream, N, st, int(g.ncell), g.start,
-                         g.cell_of, g.sx, g.sy, g.sz, r2, min_pts, core, rest, list_cnt + 1, d_tests);
+      on_coords(g, [&](auto co) {
+        hipLaunchKernelGGL(k_core_tiled<decltype(co)>, grid, block, 0, c->stream, N, st, int(g.ncell), g.start,
+                           g.cell_of, co, r2, min_pts, core, rest, list_cnt + 1, d_tests);
+      });
     }
     if (d_tests) {  // profiling level 2 only: read the counter back (synchronises)
       unsigned long long h[256];
@@ -773,16 +757,18 @@ static int dbscan_device(Ctx* c, const double* xyz, int64_t n, double eps, int32
       for (unsigned long long v : h) tot += v;
       c->timers["core_pair_tests"].launches += int64_t(tot) * 64;  // lane-tests executed
     }
-    hipLaunchKernelGGL(k_core_rest, dim3(std::min<int64_t>(8192, ceil_div(n, 64))), block, 0, c->stream,
-                       rest, list_cnt + 1, st, g.start, g.cell_of, g.sx, g.sy, g.sz, r2, min_pts, core);
+    on_coords(g, [&](auto co) {
+      hipLaunchKernelGGL(k_core_rest<decltype(co)>, dim3(std::min<int64_t>(8192, ceil_div(n, 64))), block, 0,
+                         c->stream, rest, list_cnt + 1, st, g.start, g.cell_of, co, r2, min_pts, core);
+    });
     PQ_HIP(hipGetLastError());
   }
   {
     ProfScope ps(c, "dbscan_union");
     hipLaunchKernelGGL(k_union_init, grid, block, 0, c->stream, N, parent, min_orig, flag, list_cnt);
     if (fine) {
-      hipLaunchKernelGGL(k_sub_rep, dim3(ceil_div(n, 1024)), dim3(1024), 0, c->stream, N, sub.sub_of, sub.sub_beg, sub.sub_cnt,
-                         core, g.order, parent, g.cell_of, sub.rec, run_min, list, list_cnt);
+      hipLaunchKernelGGL(k_sub_rep, dim3(ceil_div(n, 1024)), dim3(1024), 0, c->stream, N, sub.sub_of, core,
+                         g.order, parent, g.cell_of, sub.rec, run_min, list, list_cnt);
       // The number m of listed sub-cells stays on the device: the passes below are launched for the
       // upper bound (a sub-cell holds at least one point, in practice ~5) and read m themselves —
       // waves beyond it leave at once — which spares the host round trip in the middle of the step
@@ -801,24 +787,30 @@ static int dbscan_device(Ctx* c, const double* xyz, int64_t n, double eps, int32
         PQ_TRY(c->arena.get(size_t(rows) * 64, &nbr));
         {
           ProfScope pk(c, "k_hook_sub");
-          hipLaunchKernelGGL(k_hook_sub<kSubPerWaveDefault>, gw, block, 0, c->stream, list, list_cnt, g.nx, g.ny, g.start, sub.rec,
-                             g.sx, g.sy, g.sz, r2, core, parent, nbr);
+          on_coords(g, [&](auto co) {
+            hipLaunchKernelGGL((k_hook_sub<kSubPerWaveDefault, decltype(co)>), gw, block, 0, c->stream, list,
+                               list_cnt, g.nx, g.ny, g.start, sub.rec, co, r2, core, parent, nbr);
+          });
         }
         hipLaunchKernelGGL(k_flatten_reps, gl, block, 0, c->stream, list, list_cnt, parent);
         // what is left: joining the few trees per cluster. Almost every pair of neighbours
         // now shows the same root through two plain loads.
         {
           ProfScope pk(c, "k_union_sub");
-          hipLaunchKernelGGL(k_union_sub<kSubPerWaveDefault>, gw, block, 0, c->stream, list, list_cnt, nbr, sub.sub_of, sub.rec,
-                             g.sx, g.sy, g.sz, r2, core, parent);
+          on_coords(g, [&](auto co) {
+            hipLaunchKernelGGL((k_union_sub<kSubPerWaveDefault, decltype(co)>), gw, block, 0, c->stream, list,
+                               list_cnt, nbr, sub.sub_of, sub.rec, co, r2, core, parent);
+          });
         }
         hipLaunchKernelGGL(k_rep_min, gl, block, 0, c->stream, list, list_cnt, parent, run_min, min_orig);
       }
       PQ_HIP(hipGetLastError());
       hipLaunchKernelGGL(k_flatten, grid, block, 0, c->stream, N, core, parent, min_orig, flag);
     } else {
-      hipLaunchKernelGGL(k_union_points, grid, block, 0, c->stream, N, st, g.start, g.cell_of, g.sx, g.sy,
-                         g.sz, r2, core, parent);
+      on_coords(g, [&](auto co) {
+        hipLaunchKernelGGL(k_union_points<decltype(co)>, grid, block, 0, c->stream, N, st, g.start, g.cell_of, co,
+                           r2, core, parent);
+      });
       hipLaunchKernelGGL(k_flatten, grid, block, 0, c->stream, N, core, parent, static_cast<const int*>(nullptr),
                          static_cast<int32_t*>(nullptr));
       hipLaunchKernelGGL(k_point_min, grid, block, 0, c->stream, N, core, parent, g.order, min_orig);
@@ -832,9 +824,11 @@ static int dbscan_device(Ctx* c, const double* xyz, int64_t n, double eps, int32
     PQ_HIP(hipMemsetAsync(list_cnt + 1, 0, 4, c->stream));
     hipLaunchKernelGGL(k_labels, grid, block, 0, c->stream, N, core, parent, min_orig, flag, g.order,
                        labels, is_core, rest, list_cnt + 1);
-    hipLaunchKernelGGL(k_labels_border, dim3(std::min<int64_t>(8192, ceil_div(n, 64))), block, 0,
-                       c->stream, rest, list_cnt + 1, st, g.start, g.cell_of, g.sx, g.sy, g.sz, r2, core,
-                       parent, min_orig, flag, g.order, labels);
+    on_coords(g, [&](auto co) {
+      hipLaunchKernelGGL(k_labels_border<decltype(co)>, dim3(std::min<int64_t>(8192, ceil_div(n, 64))), block, 0,
+                         c->stream, rest, list_cnt + 1, st, g.start, g.cell_of, co, r2, core, parent, min_orig,
+                         flag, g.order, labels);
+    });
     PQ_HIP(hipGetLastError());
   }
   if (n_clusters) {

@@ -20,19 +20,27 @@ static double ord_val(unsigned long long k) {
 // Stage 1: one (min, max) record per block, no atomics (94 k same-address atomics
 // cost 0.56 ms in the first version of this kernel). Stage 2: one block folds the
 // records.
+// part[block][7]: min keys, max keys, and 1 if every coordinate the block saw is exactly
+// representable in fp32 (double(float(v)) == v: true for PCD / LAS derived clouds), else 0
+static constexpr int kBoxVals = 7;
 __global__ __launch_bounds__(256) void k_bbox(const double* __restrict__ xyz, int64_t n,
-                                              unsigned long long* __restrict__ part /*[grid][6]*/) {
+                                              unsigned long long* __restrict__ part /*[grid][7]*/) {
   __shared__ unsigned long long red[4][6];
+  __shared__ int red_f32[4];
   unsigned long long mn[3] = {~0ull, ~0ull, ~0ull}, mx[3] = {0, 0, 0};
+  bool f32ok = true;
   for (int64_t i = blockIdx.x * int64_t(blockDim.x) + threadIdx.x; i < n;
        i += int64_t(gridDim.x) * blockDim.x) {
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      unsigned long long k = ord_key(xyz[3 * i + a]);
+      const double v = xyz[3 * i + a];
+      f32ok = f32ok && double(float(v)) == v;
+      unsigned long long k = ord_key(v);
       mn[a] = k < mn[a] ? k : mn[a];
       mx[a] = k > mx[a] ? k : mx[a];
     }
   }
+  const bool wave_ok = __all(f32ok);
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
 #pragma unroll
@@ -49,6 +57,7 @@ __global__ __launch_bounds__(256) void k_bbox(const double* __restrict__ xyz, in
       red[w][a] = mn[a];
       red[w][3 + a] = mx[a];
     }
+    red_f32[w] = wave_ok;
   }
   __syncthreads();
   if (threadIdx.x < 6) {
@@ -57,36 +66,44 @@ __global__ __launch_bounds__(256) void k_bbox(const double* __restrict__ xyz, in
       const unsigned long long o = red[q][threadIdx.x];
       v = threadIdx.x < 3 ? (o < v ? o : v) : (o > v ? o : v);
     }
-    part[size_t(blockIdx.x) * 6 + threadIdx.x] = v;
+    part[size_t(blockIdx.x) * kBoxVals + threadIdx.x] = v;
   }
+  if (threadIdx.x == 6)
+    part[size_t(blockIdx.x) * kBoxVals + 6] = (red_f32[0] && red_f32[1] && red_f32[2] && red_f32[3]) ? 1ull : 0ull;
 }
 
+// One block folds the per-block records (the fp32 flag as a minimum: 0 wins) and, while it is
+// there, clears `zero_n` ints for the caller (the bucket counters of the binning that follows:
+// two memset launches less on the critical path).
 __global__ __launch_bounds__(256) void k_bbox_fold(const unsigned long long* __restrict__ part,
-                                                   int nblk, unsigned long long* __restrict__ out) {
-  __shared__ unsigned long long red[4][6];
-  unsigned long long v[6] = {~0ull, ~0ull, ~0ull, 0, 0, 0};
+                                                   int nblk, unsigned long long* __restrict__ out,
+                                                   int32_t* __restrict__ zero_buf, int zero_n) {
+  __shared__ unsigned long long red[4][kBoxVals];
+  for (int q = threadIdx.x; q < zero_n; q += 256) zero_buf[q] = 0;
+  unsigned long long v[kBoxVals] = {~0ull, ~0ull, ~0ull, 0, 0, 0, ~0ull};
   for (int b = threadIdx.x; b < nblk; b += 256)
 #pragma unroll
-    for (int a = 0; a < 6; ++a) {
-      const unsigned long long o = part[size_t(b) * 6 + a];
-      v[a] = a < 3 ? (o < v[a] ? o : v[a]) : (o > v[a] ? o : v[a]);
+    for (int a = 0; a < kBoxVals; ++a) {
+      const unsigned long long o = part[size_t(b) * kBoxVals + a];
+      v[a] = (a < 3 || a == 6) ? (o < v[a] ? o : v[a]) : (o > v[a] ? o : v[a]);
     }
 #pragma unroll
-  for (int a = 0; a < 6; ++a)
+  for (int a = 0; a < kBoxVals; ++a)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
       const unsigned long long o = __shfl_down(v[a], off, 64);
-      v[a] = a < 3 ? (o < v[a] ? o : v[a]) : (o > v[a] ? o : v[a]);
+      v[a] = (a < 3 || a == 6) ? (o < v[a] ? o : v[a]) : (o > v[a] ? o : v[a]);
     }
   if ((threadIdx.x & 63) == 0)
 #pragma unroll
-    for (int a = 0; a < 6; ++a) red[threadIdx.x >> 6][a] = v[a];
+    for (int a = 0; a < kBoxVals; ++a) red[threadIdx.x >> 6][a] = v[a];
   __syncthreads();
-  if (threadIdx.x < 6) {
+  if (threadIdx.x < kBoxVals) {
+    const bool is_min = threadIdx.x < 3 || threadIdx.x == 6;
     unsigned long long r = red[0][threadIdx.x];
     for (int q = 1; q < 4; ++q) {
       const unsigned long long o = red[q][threadIdx.x];
-      r = threadIdx.x < 3 ? (o < r ? o : r) : (o > r ? o : r);
+      r = is_min ? (o < r ? o : r) : (o > r ? o : r);
     }
     out[threadIdx.x] = r;
   }
@@ -317,18 +334,20 @@ int robust_box(Ctx* c, const double* xyz, int64_t n, int budget, double box[6], 
   return 0;
 }
 
-int cloud_bbox(Ctx* c, const double* xyz, int64_t n, double mn[3], double mx[3]) {
+int cloud_bbox(Ctx* c, const double* xyz, int64_t n, double mn[3], double mx[3], bool* all_f32,
+               int32_t* zero_buf, int zero_n) {
   if (n <= 0) return fail(PYQSM_EINVAL, "bounding box of an empty cloud");
   const int blocks = int(std::min<int64_t>(ceil_div(n, 256), int64_t(c->cu_count) * 4));
   unsigned long long *d_box = nullptr, *d_part = nullptr;
-  PQ_TRY(c->arena.get(6, &d_box));
-  PQ_TRY(c->arena.get(size_t(blocks) * 6, &d_part));
+  PQ_TRY(c->arena.get(kBoxVals, &d_box));
+  PQ_TRY(c->arena.get(size_t(blocks) * kBoxVals, &d_part));
   hipLaunchKernelGGL(k_bbox, dim3(blocks), dim3(256), 0, c->stream, xyz, n, d_part);
-  hipLaunchKernelGGL(k_bbox_fold, dim3(1), dim3(256), 0, c->stream, d_part, blocks, d_box);
+  hipLaunchKernelGGL(k_bbox_fold, dim3(1), dim3(256), 0, c->stream, d_part, blocks, d_box, zero_buf, zero_n);
   PQ_HIP(hipGetLastError());
-  unsigned long long h_box[6];
+  unsigned long long h_box[kBoxVals];
   PQ_HIP(hipMemcpyAsync(h_box, d_box, sizeof(h_box), hipMemcpyDeviceToHost, c->stream));
   PQ_HIP(hipStreamSynchronize(c->stream));
+  if (all_f32) *all_f32 = h_box[6] != 0;
   for (int a = 0; a < 3; ++a) {
     mn[a] = ord_val(h_box[a]);
     mx[a] = ord_val(h_box[3 + a]);
@@ -665,7 +684,7 @@ __global__ __launch_bounds__(256) void k_order_big(const int32_t* __restrict__ b
                                                    int32_t* __restrict__ cell_of,
                                                    int32_t* __restrict__ sub_of,
                                                    double* __restrict__ sx, double* __restrict__ sy,
-                                                   double* __restrict__ sz,
+                                                   double* __restrict__ sz, float4* __restrict__ p4,
                                                    int32_t* __restrict__ sub_cnt,
                                                    int32_t* __restrict__ sub_beg,
                                                    int4* __restrict__ rec) {
@@ -725,9 +744,13 @@ __global__ __launch_bounds__(256) void k_order_big(const int32_t* __restrict__ b
       order[f] = me.idx;
       cell_of[f] = c;
       sub_of[f] = b * 8 + o;
-      sx[f] = me.x;
-      sy[f] = me.y;
-      sz[f] = me.z;
+      if (p4) {
+        p4[f] = make_float4(float(me.x), float(me.y), float(me.z), 0.f);
+      } else {
+        sx[f] = me.x;
+        sy[f] = me.y;
+        sz[f] = me.z;
+      }
     }
     __syncthreads();
     if (threadIdx.x < 8)
@@ -746,29 +769,28 @@ __global__ __launch_bounds__(256) void k_order_big(const int32_t* __restrict__ b
 // is either in LDS or lands, 64 lanes wide, on 64 CONSECUTIVE counters (4 memory requests instead of
 // 64), and the directory is written exactly once, by the blocks that sort:
 //   A1  k_bk_hist     cell and octant of every point; per block an LDS histogram over the BUCKETS
-//                     (a bucket = kBkCells consecutive cell ids), flushed with one atomic per
+//                     (a bucket = 4096 or 8192 consecutive cell ids), flushed with one atomic per
 //                     non-empty (block, bucket), lanes on consecutive buckets
-//       k_bk_scan     exclusive scan of the <= 8192 bucket totals (one block)
+//       k_bk_scan     exclusive scan of the <= 16384 bucket totals (one block)
 //   A2  k_bk_scatter  the same LDS histogram again, this time returning the rank inside the block;
 //                     a block reserves its share of every bucket with one returning atomic
 //                     (same shape) and writes the 32-byte records bucket by bucket
 //   B   k_bk_sort     one block per bucket, everything in LDS: a count per cell (arrival rank) and
 //                     eight 8-bit counts per cell packed in a u64 (rank inside the octant), a block
-//                     scan of the bucket's cell counts -> the bucket's 8192 directory entries,
+//                     scan of the bucket's cell counts -> the bucket's directory entries,
 //                     written once and coalesced; every point then goes straight to its final,
 //                     octant-ordered place. Cells with more than 255 points (a packed count could
 //                     overflow) are listed for k_order_big exactly as before.
 // Same arrays as build_grid_octants leaves (the order inside a sub-cell is the arrival order of
 // atomics in both versions, and nothing downstream depends on it).
-static constexpr int kBkBits = 13;
-static constexpr int kBkCells = 1 << kBkBits;   // cells per bucket: 64 KB of packed counts in LDS
-static constexpr int kBkMax = 8192;             // buckets (LDS histogram of the A passes: 32 KB)
+static constexpr int kBkMax = 16384;            // buckets (LDS histogram of the A passes: <= 64 KB)
 static constexpr int kBkPts = 2048;             // points per block of the A passes
 static constexpr int kBkBig = 255;              // cells above this go through k_order_big
+static constexpr int kBkPer = 4;                // records a thread of k_bk_sort keeps in registers
 
 template <bool MAPPED>
 __global__ __launch_bounds__(256) void k_bk_hist(const double* __restrict__ xyz, int64_t n, GridParams g,
-                                                 int rx, int ry, int rz, AxisMap am, int nbk,
+                                                 int rx, int ry, int rz, AxisMap am, int nbk, int bits,
                                                  int32_t* __restrict__ key_tmp,
                                                  int32_t* __restrict__ tot) {
   extern __shared__ __attribute__((aligned(16))) int32_t h[];
@@ -784,7 +806,7 @@ __global__ __launch_bounds__(256) void k_bk_hist(const double* __restrict__ xyz,
                 cz = MAPPED ? am.z[r.cz] : r.cz + 1;
       const int c = (cz * g.ny + cy) * g.nx + cx;
       key_tmp[i] = (c << 3) | r.oct;
-      atomicAdd(&h[c >> kBkBits], 1);  // LDS
+      atomicAdd(&h[c >> bits], 1);  // LDS
     }
   }
   __syncthreads();
@@ -799,9 +821,9 @@ __global__ __launch_bounds__(1024) void k_bk_scan(int nbk, const int32_t* __rest
                                                   int32_t* __restrict__ bstart,
                                                   int32_t* __restrict__ cursor) {
   __shared__ int32_t wsum[16];
-  const int per = (nbk + 1023) / 1024;  // <= 8
+  const int per = (nbk + 1023) / 1024;  // <= 16
   const int b0 = threadIdx.x * per;
-  int32_t v[8], s = 0;
+  int32_t v[16], s = 0;
   for (int k = 0; k < per; ++k) {
     v[k] = b0 + k < nbk ? tot[b0 + k] : 0;
     s += v[k];
@@ -828,7 +850,7 @@ __global__ __launch_bounds__(1024) void k_bk_scan(int nbk, const int32_t* __rest
 }
 
 __global__ __launch_bounds__(256) void k_bk_scatter(const double* __restrict__ xyz, int64_t n, int nbk,
-                                                    const int32_t* __restrict__ key_tmp,
+                                                    int bits, const int32_t* __restrict__ key_tmp,
                                                     int32_t* __restrict__ cursor,
                                                     PointRec* __restrict__ bucketed) {
   extern __shared__ __attribute__((aligned(16))) int32_t h[];
@@ -840,7 +862,7 @@ __global__ __launch_bounds__(256) void k_bk_scatter(const double* __restrict__ x
   for (int k = 0; k < kBkPts / 256; ++k) {
     const int64_t i = base + k * 256 + threadIdx.x;
     key[k] = i < n ? key_tmp[i] : -1;
-    lr[k] = key[k] >= 0 ? atomicAdd(&h[key[k] >> (3 + kBkBits)], 1) : 0;  // rank inside this block's share
+    lr[k] = key[k] >= 0 ? atomicAdd(&h[key[k] >> (3 + bits)], 1) : 0;  // rank inside this block's share
   }
   __syncthreads();
   for (int b = threadIdx.x; b < nbk; b += 256) {
@@ -858,7 +880,7 @@ __global__ __launch_bounds__(256) void k_bk_scatter(const double* __restrict__ x
     r.z = xyz[3 * i + 2];
     r.idx = int(i);
     r.key = key[k];
-    bucketed[h[key[k] >> (3 + kBkBits)] + lr[k]] = r;
+    bucketed[h[key[k] >> (3 + bits)] + lr[k]] = r;
   }
 }
 
@@ -870,37 +892,36 @@ __device__ __forceinline__ int bytes_below(unsigned long long x, int o) {
   return int((x + (x >> 32)) & 0xFFFFull);
 }
 
+template <int BITS>
 struct BkLds {
-  unsigned long long oct[kBkCells];  // eight 8-bit counts per cell
-  int32_t cnt[kBkCells];             // points per cell, then (in place) the cell's offset in the bucket
-  uint32_t big[kBkCells / 32];       // cells with more than kBkBig points
+  unsigned long long oct[1 << BITS];  // eight 8-bit counts per cell
+  int32_t cnt[1 << BITS];             // points per cell, then (in place) the cell's offset in the bucket
+  uint32_t big[(1 << BITS) / 32];     // cells with more than kBkBig points
   int32_t wsum[16];
 };
 
-__global__ __launch_bounds__(1024) void k_bk_sort(int64_t ncell1 /*directory entries: ncell + 1*/,
-                                                  const int32_t* __restrict__ bstart,
-                                                  const PointRec* __restrict__ bucketed,
-                                                  int32_t* __restrict__ rank_tmp,
-                                                  uint8_t* __restrict__ oct_rank,
-                                                  int32_t* __restrict__ start,
-                                                  int32_t* __restrict__ order,
-                                                  int32_t* __restrict__ cell_of,
-                                                  int32_t* __restrict__ sub_of,
-                                                  double* __restrict__ sx, double* __restrict__ sy,
-                                                  double* __restrict__ sz,
-                                                  int32_t* __restrict__ sub_cnt,
-                                                  int32_t* __restrict__ sub_beg,
-                                                  int4* __restrict__ rec, PointRec* __restrict__ keyed,
-                                                  int32_t* __restrict__ big_list,
-                                                  int32_t* __restrict__ big_cnt) {
-  __shared__ BkLds L;
+// One block per bucket of 2^BITS cells, a thread per eight cells (BITS = 12: 512 threads and 49 KB of
+// LDS, three blocks per CU; BITS = 13 for directories beyond 2^26 cells). A bucket of at most
+// kBkPer points per thread — every bucket of a scan — keeps its records and ranks in registers
+// between the two sweeps: the block's chain of dependent memory round trips is then bstart ->
+// records -> stores. Larger buckets go through rank_tmp / oct_rank in global memory.
+template <int BITS>
+__global__ __launch_bounds__((1 << BITS) / 8) void k_bk_sort(
+    int64_t ncell1 /*directory entries: ncell + 1*/, const int32_t* __restrict__ bstart,
+    const PointRec* __restrict__ bucketed, int32_t* __restrict__ rank_tmp, uint8_t* __restrict__ oct_rank,
+    int32_t* __restrict__ start, int32_t* __restrict__ order, int32_t* __restrict__ cell_of,
+    int32_t* __restrict__ sub_of, double* __restrict__ sx, double* __restrict__ sy, double* __restrict__ sz,
+    float4* __restrict__ p4 /*non-null: fp32 records instead of sx / sy / sz*/, int4* __restrict__ rec,
+    PointRec* __restrict__ keyed, int32_t* __restrict__ big_list, int32_t* __restrict__ big_cnt) {
+  constexpr int CELLS = 1 << BITS, T = CELLS / 8;
+  __shared__ BkLds<BITS> L;
   const int bk = blockIdx.x, t = threadIdx.x;
   const int s = bstart[bk], e = bstart[bk + 1];
-  const int64_t c0 = int64_t(bk) << kBkBits;  // first cell (directory entry) of the bucket
+  const int64_t c0 = int64_t(bk) << BITS;  // first cell (directory entry) of the bucket
   if (s == e) {  // nothing in the bucket: its directory entries all say "the next point is s"
 #pragma unroll
-    for (int k = 0; k < kBkCells / 1024; k += 4) {
-      const int64_t cidx = c0 + int64_t(k / 4 * 1024 + t) * 4;
+    for (int k = 0; k < 2; ++k) {
+      const int64_t cidx = c0 + int64_t(k * T + t) * 4;
       if (cidx + 3 < ncell1) {
         *reinterpret_cast<int4*>(start + cidx) = make_int4(s, s, s, s);
       } else {
@@ -910,19 +931,41 @@ __global__ __launch_bounds__(1024) void k_bk_sort(int64_t ncell1 /*directory ent
     }
     return;
   }
-  for (int q = t; q < kBkCells; q += 1024) {
-    L.oct[q] = 0ull;
-    L.cnt[q] = 0;
+  const bool inreg = e - s <= T * kBkPer;  // block-uniform
+  PointRec me[kBkPer];
+  int rr[kBkPer], r8[kBkPer];
+  if (inreg) {  // issue the loads before the LDS is cleared
+#pragma unroll
+    for (int k = 0; k < kBkPer; ++k) {
+      const int j = s + k * T + t;
+      me[k].key = -1;
+      if (j < e) me[k] = bucketed[j];
+    }
   }
-  if (t < kBkCells / 32) L.big[t] = 0u;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    L.oct[k * T + t] = 0ull;
+    L.cnt[k * T + t] = 0;
+  }
+  if (t < CELLS / 32) L.big[t] = 0u;
   __syncthreads();
   // sweep 1: arrival rank in the cell and in the octant
-  for (int j = s + t; j < e; j += 1024) {
-    const int key = bucketed[j].key;
-    const int cl = (key >> 3) & (kBkCells - 1), o = key & 7;
-    rank_tmp[j] = atomicAdd(&L.cnt[cl], 1);
-    const unsigned long long old = atomicAdd(&L.oct[cl], 1ull << (8 * o));
-    oct_rank[j] = uint8_t(old >> (8 * o));  // meaningful only in cells of at most kBkBig points
+  if (inreg) {
+#pragma unroll
+    for (int k = 0; k < kBkPer; ++k) {
+      if (me[k].key < 0) continue;
+      const int cl = (me[k].key >> 3) & (CELLS - 1), o = me[k].key & 7;
+      rr[k] = atomicAdd(&L.cnt[cl], 1);
+      r8[k] = int((atomicAdd(&L.oct[cl], 1ull << (8 * o)) >> (8 * o)) & 255ull);
+    }
+  } else {
+    for (int j = s + t; j < e; j += T) {
+      const int key = bucketed[j].key;
+      const int cl = (key >> 3) & (CELLS - 1), o = key & 7;
+      rank_tmp[j] = atomicAdd(&L.cnt[cl], 1);
+      const unsigned long long old = atomicAdd(&L.oct[cl], 1ull << (8 * o));
+      oct_rank[j] = uint8_t(old >> (8 * o));  // meaningful only in cells of at most kBkBig points
+    }
   }
   __syncthreads();
   // the bucket's cells: thread t owns eight consecutive ones
@@ -979,29 +1022,37 @@ __global__ __launch_bounds__(1024) void k_bk_sort(int64_t ncell1 /*directory ent
 #pragma unroll
     for (int o = 0; o < 8; ++o) {
       const int cnt = int((c64 >> (8 * o)) & 255ull);
-      sub_beg[size_t(b) * 8 + o] = r2;
-      sub_cnt[size_t(b) * 8 + o] = cnt;
       rec[size_t(b) * 8 + o] = make_int4(r2, cnt, -1, 0);
       r2 += cnt;
     }
   }
   __syncthreads();
   // sweep 2: every point to its final place (big cells: to the cell's run of `keyed`, in arrival order)
-  for (int j = s + t; j < e; j += 1024) {
-    const PointRec me = bucketed[j];
-    const int cl = (me.key >> 3) & (kBkCells - 1), o = me.key & 7;
+  auto place = [&](const PointRec& p, int arrival, int in_oct) {
+    const int cl = (p.key >> 3) & (CELLS - 1), o = p.key & 7;
     const int b = s + L.cnt[cl];
     if ((L.big[cl >> 5] >> (cl & 31)) & 1u) {
-      keyed[b + rank_tmp[j]] = me;
-      continue;
+      keyed[b + arrival] = p;
+      return;
     }
-    const int f = b + bytes_below(L.oct[cl], o) + int(oct_rank[j]);
-    order[f] = me.idx;
-    cell_of[f] = me.key >> 3;
+    const int f = b + bytes_below(L.oct[cl], o) + in_oct;
+    order[f] = p.idx;
+    cell_of[f] = p.key >> 3;
     sub_of[f] = b * 8 + o;
-    sx[f] = me.x;
-    sy[f] = me.y;
-    sz[f] = me.z;
+    if (p4) {
+      p4[f] = make_float4(float(p.x), float(p.y), float(p.z), 0.f);
+    } else {
+      sx[f] = p.x;
+      sy[f] = p.y;
+      sz[f] = p.z;
+    }
+  };
+  if (inreg) {
+#pragma unroll
+    for (int k = 0; k < kBkPer; ++k)
+      if (me[k].key >= 0) place(me[k], rr[k], r8[k]);
+  } else {
+    for (int j = s + t; j < e; j += T) place(bucketed[j], rank_tmp[j], int(oct_rank[j]));
   }
 }
 
@@ -1013,7 +1064,16 @@ int build_grid_octants(Ctx* c, const double* xyz, int64_t n, double min_cell, in
   if (!(min_cell > 0) || !std::isfinite(min_cell))
     return fail(PYQSM_EINVAL, "cell edge must be positive and finite");
   double mn[3], mx[3];
-  PQ_TRY(cloud_bbox(c, xyz, n, mn, mx));
+  // the bucket totals and the big-cell counter of the two-level sort below: cleared by the
+  // bounding box's fold kernel on its way (two memset launches less)
+  int32_t* tot_big = nullptr;
+  PQ_TRY(c->arena.get(size_t(kBkMax) + 1, &tot_big));
+  bool all_f32 = false;
+  PQ_TRY(cloud_bbox(c, xyz, n, mn, mx, &all_f32, tot_big, kBkMax + 1));
+  {
+    const char* f32_env = getenv("PYQSM_COORD_F32");  // "0": keep fp64 storage (A/B comparisons)
+    if (f32_env && !strcmp(f32_env, "0")) all_f32 = false;
+  }
   const dim3 grid(ceil_div(n, 256)), blk(256);
   double cell = min_cell;
   int raw[3], dims[3];
@@ -1076,12 +1136,26 @@ int build_grid_octants(Ctx* c, const double* xyz, int64_t n, double min_cell, in
   g->ncell = int64_t(dims[0]) * dims[1] * dims[2];
   int32_t *cell_tmp, *rank_tmp, *big_list, *big_cnt;
   PointRec* keyed;
+  // Two-level counting sort (k_bk_*): no scattered global atomics, the directory written once.
+  // PYQSM_DBSCAN_BIN=atomic keeps round 2's one-atomic-per-point path (A/B comparisons); grids of
+  // more than kBkMax buckets (2^27 cells) keep it too.
+  const int bits = g->ncell + 1 <= (int64_t(kBkMax) << 12) ? 12 : 13;
+  const int64_t nbk = (g->ncell + (int64_t(1) << bits)) >> bits;  // ceil((ncell + 1) / bucket)
+  const char* bin_env = getenv("PYQSM_DBSCAN_BIN");
+  const bool bucketed_path = nbk <= kBkMax && !(bin_env && !strcmp(bin_env, "atomic"));
+  // fp32 records when the input allows it (round 2's path keeps fp64 arrays)
+  g->p4 = nullptr;
+  g->sx = g->sy = g->sz = nullptr;
   PQ_TRY(c->arena.get(size_t(g->ncell) + 1, &g->start));
   PQ_TRY(c->arena.get(size_t(n), &g->order));
   PQ_TRY(c->arena.get(size_t(n), &g->cell_of));
-  PQ_TRY(c->arena.get(size_t(n), &g->sx));
-  PQ_TRY(c->arena.get(size_t(n), &g->sy));
-  PQ_TRY(c->arena.get(size_t(n), &g->sz));
+  if (all_f32 && bucketed_path) {
+    PQ_TRY(c->arena.get(size_t(n), &g->p4));
+  } else {
+    PQ_TRY(c->arena.get(size_t(n), &g->sx));
+    PQ_TRY(c->arena.get(size_t(n), &g->sy));
+    PQ_TRY(c->arena.get(size_t(n), &g->sz));
+  }
   PQ_TRY(c->arena.get(size_t(n), &cell_tmp));
   PQ_TRY(c->arena.get(size_t(n), &rank_tmp));
   PQ_TRY(c->arena.get(size_t(n), &keyed));
@@ -1090,41 +1164,39 @@ int build_grid_octants(Ctx* c, const double* xyz, int64_t n, double min_cell, in
   PQ_TRY(c->arena.get(size_t(n), &sub->sub_of));
   PQ_TRY(c->arena.get(size_t(n) * 8, &sub->rec));
   PQ_TRY(c->arena.get(size_t(n) / kBigCell + 2, &big_list));
-  PQ_TRY(c->arena.get(1, &big_cnt));
-  PQ_HIP(hipMemsetAsync(big_cnt, 0, 4, c->stream));
+  big_cnt = tot_big + kBkMax;
   GridParams gp{g->minx, g->miny, g->minz, g->inv_cell, g->nx, g->ny, g->nz};
-  // Two-level counting sort (k_bk_*): no scattered global atomics, the directory written once.
-  // PYQSM_DBSCAN_BIN=atomic keeps round 2's one-atomic-per-point path (A/B comparisons); grids of
-  // more than kBkMax buckets (2^26 cells) keep it too.
-  const int64_t nbk = (g->ncell + 1 + kBkCells - 1) >> kBkBits;
-  const char* bin_env = getenv("PYQSM_DBSCAN_BIN");
-  if (nbk <= kBkMax && !(bin_env && !strcmp(bin_env, "atomic"))) {
-    int32_t *tot, *bstart, *cursor;
+  if (bucketed_path) {
+    int32_t *tot = tot_big, *bstart, *cursor;
     uint8_t* oct_rank;
     PointRec* bucketed;
-    PQ_TRY(c->arena.get(size_t(nbk), &tot));
     PQ_TRY(c->arena.get(size_t(nbk) + 1, &bstart));
     PQ_TRY(c->arena.get(size_t(nbk), &cursor));
     PQ_TRY(c->arena.get(size_t(n), &oct_rank));
     PQ_TRY(c->arena.get(size_t(n), &bucketed));
-    PQ_HIP(hipMemsetAsync(tot, 0, size_t(nbk) * 4, c->stream));
     const dim3 ga(ceil_div(n, kBkPts));
     const size_t lds = size_t(nbk) * 4;
     if (mapped)
       hipLaunchKernelGGL(k_bk_hist<true>, ga, blk, lds, c->stream, xyz, n, gp, raw[0], raw[1], raw[2], am,
-                         int(nbk), cell_tmp, tot);
+                         int(nbk), bits, cell_tmp, tot);
     else
       hipLaunchKernelGGL(k_bk_hist<false>, ga, blk, lds, c->stream, xyz, n, gp, raw[0], raw[1], raw[2], am,
-                         int(nbk), cell_tmp, tot);
+                         int(nbk), bits, cell_tmp, tot);
     hipLaunchKernelGGL(k_bk_scan, dim3(1), dim3(1024), 0, c->stream, int(nbk), tot, bstart, cursor);
-    hipLaunchKernelGGL(k_bk_scatter, ga, blk, lds, c->stream, xyz, n, int(nbk), cell_tmp, cursor, bucketed);
-    hipLaunchKernelGGL(k_bk_sort, dim3(unsigned(nbk)), dim3(1024), 0, c->stream, g->ncell + 1, bstart, bucketed,
-                       rank_tmp, oct_rank, g->start, g->order, g->cell_of, sub->sub_of, g->sx, g->sy, g->sz,
-                       sub->sub_cnt, sub->sub_beg, sub->rec, keyed, big_list, big_cnt);
+    hipLaunchKernelGGL(k_bk_scatter, ga, blk, lds, c->stream, xyz, n, int(nbk), bits, cell_tmp, cursor,
+                       bucketed);
+    if (bits == 12)
+      hipLaunchKernelGGL(k_bk_sort<12>, dim3(unsigned(nbk)), dim3(512), 0, c->stream, g->ncell + 1, bstart,
+                         bucketed, rank_tmp, oct_rank, g->start, g->order, g->cell_of, sub->sub_of, g->sx, g->sy,
+                         g->sz, g->p4, sub->rec, keyed, big_list, big_cnt);
+    else
+      hipLaunchKernelGGL(k_bk_sort<13>, dim3(unsigned(nbk)), dim3(1024), 0, c->stream, g->ncell + 1, bstart,
+                         bucketed, rank_tmp, oct_rank, g->start, g->order, g->cell_of, sub->sub_of, g->sx, g->sy,
+                         g->sz, g->p4, sub->rec, keyed, big_list, big_cnt);
     PQ_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_order_big, dim3(unsigned(std::min<int64_t>(n / kBigCell + 1, 2048))), blk, 0,
                        c->stream, big_list, big_cnt, g->start, keyed, g->order, g->cell_of, sub->sub_of,
-                       g->sx, g->sy, g->sz, sub->sub_cnt, sub->sub_beg, sub->rec);
+                       g->sx, g->sy, g->sz, g->p4, sub->sub_cnt, sub->sub_beg, sub->rec);
     PQ_HIP(hipGetLastError());
     return 0;
   }
@@ -1146,7 +1218,7 @@ int build_grid_octants(Ctx* c, const double* xyz, int64_t n, double min_cell, in
   // grid reads their number on the device, so that no host round trip is needed
   hipLaunchKernelGGL(k_order_big, dim3(unsigned(std::min<int64_t>(n / kBigCell + 1, 2048))), blk, 0,
                      c->stream, big_list, big_cnt, g->start, keyed, g->order, g->cell_of, sub->sub_of,
-                     g->sx, g->sy, g->sz, sub->sub_cnt, sub->sub_beg, sub->rec);
+                     g->sx, g->sy, g->sz, g->p4, sub->sub_cnt, sub->sub_beg, sub->rec);
   PQ_HIP(hipGetLastError());
   return 0;
 }

@@ -20,7 +20,12 @@ struct DevGrid {
   int32_t* start;        // [ncell + 1] first sorted position of each cell
   int32_t* order;        // [n] sorted position -> original index
   int32_t* cell_of;      // [n] cell id of each sorted position
-  double *sx, *sy, *sz;  // [n] sorted coordinates
+  double *sx, *sy, *sz;  // [n] sorted coordinates (fp64 storage)
+  // [n] sorted coordinates as one 16-byte (x, y, z, 0) fp32 record per point, INSTEAD of sx / sy /
+  // sz (those are then null): only when every input coordinate is exactly representable in fp32
+  // (cloud_bbox's flag), so that double(p4[q].x) IS the input value and every fp64 predicate
+  // evaluated on it is bit-identical. Half the bytes, and a gather touches one line, not three.
+  float4* p4 = nullptr;
   // build_grid only: per block of its counting pass, the points that were the first of their
   // cell — their sum is the number of occupied cells (count_occupied), without a pass over
   // the ncell-long start array
@@ -37,8 +42,11 @@ struct DevGrid {
 int build_grid(Ctx* c, const double* xyz, int64_t n, double min_cell, int64_t max_cells,
                DevGrid* g, const double* bbox = nullptr);
 
-// Bounding box of the cloud (one reduction kernel + a 48-byte read-back).
-int cloud_bbox(Ctx* c, const double* xyz, int64_t n, double mn[3], double mx[3]);
+// Bounding box of the cloud (one reduction kernel, a one-block fold, a 56-byte read-back).
+// *all_f32 (optional): every coordinate is exactly representable in fp32. zero_buf / zero_n
+// (optional): ints the fold kernel clears on the way (saves the caller a memset launch).
+int cloud_bbox(Ctx* c, const double* xyz, int64_t n, double mn[3], double mx[3], bool* all_f32 = nullptr,
+               int32_t* zero_buf = nullptr, int zero_n = 0);
 // Shrinks box (min xyz, max xyz) to the part of the cloud that is left when at most `budget`
 // points in sparse tails are given up (they clamp into the outermost cells of a grid built over
 // the box); *outside = how many the last cut gave up (0: box unchanged).
@@ -52,6 +60,49 @@ int probe_occupancy(Ctx* c, const double* xyz, int64_t n, const double box[6], d
 
 struct Stencil {
   int nx, nxy;
+};
+
+// ---- how the neighbourhood kernels read a sorted point ------------------------------------
+// Both forms hand out fp64 values and evaluate d2 = ((dx*dx) + dy*dy) + dz*dz with separately
+// rounded products (the library is built with -ffp-contract=off): the predicate does not know
+// how the coordinates were stored.
+__device__ __forceinline__ double sqdist3(double ax, double ay, double az, double bx, double by, double bz) {
+  const double t0 = ax - bx, t1 = ay - by, t2 = az - bz;
+  double d = t0 * t0;
+  d = d + t1 * t1;
+  d = d + t2 * t2;
+  return d;
+}
+struct CoordsF64 {
+  const double *x, *y, *z;
+  __device__ __forceinline__ void get(int q, double& a, double& b, double& c) const {
+    a = x[q];
+    b = y[q];
+    c = z[q];
+  }
+  __device__ __forceinline__ double d2(int q, double px, double py, double pz) const {
+    return sqdist3(px, py, pz, x[q], y[q], z[q]);
+  }
+  __device__ __forceinline__ double d2(int a, int q) const {
+    return sqdist3(x[a], y[a], z[a], x[q], y[q], z[q]);
+  }
+};
+struct CoordsF32 {
+  const float4* p;
+  __device__ __forceinline__ void get(int q, double& a, double& b, double& c) const {
+    const float4 v = p[q];
+    a = double(v.x);
+    b = double(v.y);
+    c = double(v.z);
+  }
+  __device__ __forceinline__ double d2(int q, double px, double py, double pz) const {
+    const float4 v = p[q];
+    return sqdist3(px, py, pz, double(v.x), double(v.y), double(v.z));
+  }
+  __device__ __forceinline__ double d2(int a, int q) const {
+    const float4 u = p[a], v = p[q];
+    return sqdist3(double(u.x), double(u.y), double(u.z), double(v.x), double(v.y), double(v.z));
+  }
 };
 
 // ---- wave-tiled traversal -----------------------------------------------------------
@@ -112,6 +163,15 @@ __device__ __forceinline__ Tile wave_tile(int p0, int n, Stencil st, int ncell,
     t.total += t.qe[r] - t.qb[r];
   }
   return t;
+}
+
+// Calls fn(CoordsF32{...}) or fn(CoordsF64{...}) for the storage form the grid holds.
+template <class F>
+inline void on_coords(const DevGrid& g, F&& fn) {
+  if (g.p4)
+    fn(CoordsF32{g.p4});
+  else
+    fn(CoordsF64{g.sx, g.sy, g.sz});
 }
 
 // Octant sub-cells: the points of every cell re-sorted by the octant (half cell per axis)

@@ -54,14 +54,7 @@ struct KnnGrid {
   double minx, miny, minz;  // origin of the interior cells (cell 1 starts here)
 };
 
-__device__ __forceinline__ double sqdist3(double ax, double ay, double az, double bx, double by,
-                                          double bz) {
-  double t0 = ax - bx, t1 = ay - by, t2 = az - bz;
-  double d = t0 * t0;
-  d = d + t1 * t1;
-  d = d + t2 * t2;
-  return d;
-}
+// sqdist3: grid.hpp
 
 // T = threads per block (LDS holds T columns of k (d2, id) pairs).
 template <int T>

@@ -220,3 +220,49 @@ def test_points_exactly_eps_apart_under_both_radius_rules(gpu):
     s_lab, s_core = hip.dbscan(Q, 0.1, 10, device=gpu, radius_inclusive=False)
     o_lab, o_core = oracle.dbscan(Q, 0.1, 10, radius_inclusive=False)
     assert np.array_equal(s_lab, o_lab) and np.array_equal(s_core, o_core)
+
+
+def test_fp32_records_and_the_fp64_fallback(gpu, monkeypatch):
+    """Coordinates that are all exactly representable in fp32 (every PCD / LAS derived cloud, every
+    fixture) are kept as one 16-byte fp32 record per sorted point and widened to fp64 in registers:
+    the predicate sees the input values, so labels and core set are those of the fp64 arrays — and
+    of the oracle. One coordinate that is NOT representable sends the whole call to fp64 storage."""
+    P = synth.forest(60_000, seed=21)
+    assert np.array_equal(P, P.astype(np.float32).astype(np.float64))
+    lab0, core0 = oracle.dbscan(P, 0.1, 10)
+
+    def run(Q):
+        hip.prof_enable(True, gpu)
+        hip.prof_reset(gpu)
+        lab, core = hip.dbscan(Q, 0.1, 10, device=gpu)
+        used = hip.prof_get("dbscan_f32_records", gpu)[1]
+        hip.prof_enable(False, gpu)
+        return lab, core, used
+
+    lab, core, used = run(P)
+    assert used == 1 and np.array_equal(lab, lab0) and np.array_equal(core, core0)
+    monkeypatch.setenv("PYQSM_COORD_F32", "0")                            # the same cloud in fp64 arrays
+    lab, core, used = run(P)
+    assert used == 0 and np.array_equal(lab, lab0) and np.array_equal(core, core0)
+    monkeypatch.delenv("PYQSM_COORD_F32")
+    # not representable: a jitter far below fp32 resolution that still moves points across eps
+    rng = np.random.default_rng(2)
+    Q = P + rng.uniform(-1e-9, 1e-9, P.shape)
+    assert not np.array_equal(Q, Q.astype(np.float32).astype(np.float64))
+    lab, core, used = run(Q)
+    labq, coreq = oracle.dbscan(Q, 0.1, 10)
+    assert used == 0 and np.array_equal(lab, labq) and np.array_equal(core, coreq)
+    # a single such coordinate is enough for the fallback
+    R = P.copy()
+    R[12345, 1] = np.nextafter(R[12345, 1], np.inf)
+    lab, core, used = run(R)
+    labr, corer = oracle.dbscan(R, 0.1, 10)
+    assert used == 0 and np.array_equal(lab, labr) and np.array_equal(core, corer)
+    # exact-eps pairs survive the narrower storage (values are identical, so is d2 <= eps^2)
+    g = np.arange(10) * 0.5
+    Lat = np.array(np.meshgrid(g, g, g, indexing="ij")).reshape(3, -1).T.copy()
+    lab, core, used = run(Lat)
+    assert used == 1
+    lab2, core2 = hip.dbscan(Lat, 0.5, 7, device=gpu)
+    lo, co = oracle.dbscan(Lat, 0.5, 7)
+    assert np.array_equal(lab2, lo) and np.array_equal(core2, co)
