@@ -157,7 +157,10 @@ __global__ __launch_bounds__(256) void k_core_tiled(int n, Stencil st, int ncell
       }
     }
   }
-  if (live && cnt >= 0) core[p] = cnt >= min_pts;
+  if (live && cnt >= 0) {
+    core[p] = cnt >= min_pts;
+    co.mark_core(p, cnt >= min_pts);
+  }
   if (tests && lane == 0) atomicAdd(tests + (blockIdx.x & 255), static_cast<unsigned long long>(staged));
 }
 
@@ -188,7 +191,10 @@ __global__ __launch_bounds__(256) void k_core_rest(const int32_t* __restrict__ r
           cnt += __popcll(__ballot(hit));
         }
       }
-    if (lane == 0) core[p] = cnt >= min_pts;
+    if (lane == 0) {
+      core[p] = cnt >= min_pts;
+      co.mark_core(p, cnt >= min_pts);
+    }
   }
 }
 
@@ -425,7 +431,7 @@ __global__ __launch_bounds__(256) void k_hook_sub(const int4* __restrict__ list,
         bool hit = false;
         if (idx < pairs) {
           const int a = p + idx / nb, q = qb + idx % nb;
-          hit = core[a] && core[q] && co.d2(a, q) <= r2;
+          hit = co.core_pair_within(a, q, core, r2);
         }
         found = __ballot(hit) != 0;
       }
@@ -500,7 +506,7 @@ __global__ __launch_bounds__(256) void k_union_sub(const int4* __restrict__ list
         bool hit = false;
         if (idx < pairs) {
           const int a = p + idx / nb, q = qb + idx % nb;
-          hit = core[a] && core[q] && co.d2(a, q) <= r2;
+          hit = co.core_pair_within(a, q, core, r2);
         }
         found = __ballot(hit) != 0;
       }

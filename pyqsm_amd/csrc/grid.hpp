@@ -86,9 +86,14 @@ struct CoordsF64 {
   __device__ __forceinline__ double d2(int a, int q) const {
     return sqdist3(x[a], y[a], z[a], x[q], y[q], z[q]);
   }
+  // core flag of a sorted point: lives in its own byte array for this storage form
+  __device__ __forceinline__ void mark_core(int, bool) const {}
+  __device__ __forceinline__ bool core_pair_within(int a, int q, const uint8_t* __restrict__ core, double r2) const {
+    return core[a] && core[q] && d2(a, q) <= r2;
+  }
 };
 struct CoordsF32 {
-  const float4* p;
+  float4* p;  // .w: 1.0f once the point is known to be a core point (k_core_*), else 0
   __device__ __forceinline__ void get(int q, double& a, double& b, double& c) const {
     const float4 v = p[q];
     a = double(v.x);
@@ -102,6 +107,16 @@ struct CoordsF32 {
   __device__ __forceinline__ double d2(int a, int q) const {
     const float4 u = p[a], v = p[q];
     return sqdist3(double(u.x), double(u.y), double(u.z), double(v.x), double(v.y), double(v.z));
+  }
+  // The core flag rides in the record's fourth word: the pair tests of the union phase then
+  // touch one line per point (coordinates AND flag) instead of two.
+  __device__ __forceinline__ void mark_core(int q, bool is_core) const {
+    reinterpret_cast<float*>(p)[size_t(q) * 4 + 3] = is_core ? 1.0f : 0.0f;
+  }
+  __device__ __forceinline__ bool core_pair_within(int a, int q, const uint8_t* __restrict__, double r2) const {
+    const float4 u = p[a], v = p[q];
+    return u.w != 0.0f && v.w != 0.0f &&
+           sqdist3(double(u.x), double(u.y), double(u.z), double(v.x), double(v.y), double(v.z)) <= r2;
   }
 };
 
