@@ -357,6 +357,8 @@ int cloud_bbox(Ctx* c, const double* xyz, int64_t n, double mn[3], double mx[3],
   return 0;
 }
 
+static int build_grid_bucketed(Ctx* c, const double* xyz, int64_t n, DevGrid* g, bool* done);
+
 int build_grid(Ctx* c, const double* xyz, int64_t n, double min_cell, int64_t max_cells,
                DevGrid* g, const double* bbox) {
   if (n <= 0) return fail(PYQSM_EINVAL, "build_grid: empty cloud");
@@ -402,6 +404,12 @@ int build_grid(Ctx* c, const double* xyz, int64_t n, double min_cell, int64_t ma
   PQ_TRY(c->arena.get(size_t(n), &g->sx));
   PQ_TRY(c->arena.get(size_t(n), &g->sy));
   PQ_TRY(c->arena.get(size_t(n), &g->sz));
+  g->p4 = nullptr;
+  {  // two-level counting sort: no scattered atomics, no memset and no scan of the directory
+    bool done = false;
+    PQ_TRY(build_grid_bucketed(c, xyz, n, g, &done));
+    if (done) return 0;
+  }
   PQ_TRY(c->arena.get(size_t(n), &cell_tmp));
   PQ_TRY(c->arena.get(size_t(n), &rank_tmp));
   PQ_HIP(hipMemsetAsync(g->start, 0, (size_t(g->ncell) + 1) * 4, c->stream));
@@ -788,7 +796,9 @@ static constexpr int kBkPts = 2048;             // points per block of the A pas
 static constexpr int kBkBig = 255;              // cells above this go through k_order_big
 static constexpr int kBkPer = 4;                // records a thread of k_bk_sort keeps in registers
 
-template <bool MAPPED>
+// MODE 0: cell and octant on the raw grid; 1: the same through the axis-compression maps;
+// 2: cell only, clamped into the grid's box (build_grid: what kNN and the radius queries bin with)
+template <int MODE>
 __global__ __launch_bounds__(256) void k_bk_hist(const double* __restrict__ xyz, int64_t n, GridParams g,
                                                  int rx, int ry, int rz, AxisMap am, int nbk, int bits,
                                                  int32_t* __restrict__ key_tmp,
@@ -801,11 +811,17 @@ __global__ __launch_bounds__(256) void k_bk_hist(const double* __restrict__ xyz,
   for (int k = 0; k < kBkPts / 256; ++k) {
     const int64_t i = base + k * 256 + threadIdx.x;
     if (i < n) {
-      const RawCell r = raw_cell(g, rx, ry, rz, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
-      const int cx = MAPPED ? am.x[r.cx] : r.cx + 1, cy = MAPPED ? am.y[r.cy] : r.cy + 1,
-                cz = MAPPED ? am.z[r.cz] : r.cz + 1;
-      const int c = (cz * g.ny + cy) * g.nx + cx;
-      key_tmp[i] = (c << 3) | r.oct;
+      int c, oct = 0;
+      if (MODE == 2) {
+        c = cell_index(g, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
+      } else {
+        const RawCell r = raw_cell(g, rx, ry, rz, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
+        const int cx = MODE == 1 ? am.x[r.cx] : r.cx + 1, cy = MODE == 1 ? am.y[r.cy] : r.cy + 1,
+                  cz = MODE == 1 ? am.z[r.cz] : r.cz + 1;
+        c = (cz * g.ny + cy) * g.nx + cx;
+        oct = r.oct;
+      }
+      key_tmp[i] = (c << 3) | oct;
       atomicAdd(&h[c >> bits], 1);  // LDS
     }
   }
@@ -1056,6 +1072,163 @@ __global__ __launch_bounds__((1 << BITS) / 8) void k_bk_sort(
   }
 }
 
+// The same second level without octants (build_grid): a count per cell is all there is, so a bucket
+// of 2^BITS cells needs 4 bytes of LDS per cell, the arrival rank IS the place inside the cell, and
+// no cell is too big. occ[bucket] = occupied cells of the bucket (count_occupied adds them up).
+template <int BITS>
+__global__ __launch_bounds__((1 << BITS) / 8) void k_bk_sort_plain(
+    int64_t ncell1, const int32_t* __restrict__ bstart, const PointRec* __restrict__ bucketed,
+    int32_t* __restrict__ rank_tmp, int32_t* __restrict__ start, int32_t* __restrict__ order,
+    int32_t* __restrict__ cell_of, double* __restrict__ sx, double* __restrict__ sy, double* __restrict__ sz,
+    int32_t* __restrict__ occ) {
+  constexpr int CELLS = 1 << BITS, T = CELLS / 8;
+  __shared__ int32_t cnt[CELLS];
+  __shared__ int32_t wsum[16], wocc[16];
+  const int bk = blockIdx.x, t = threadIdx.x;
+  const int s = bstart[bk], e = bstart[bk + 1];
+  const int64_t c0 = int64_t(bk) << BITS;
+  if (s == e) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int64_t cidx = c0 + int64_t(k * T + t) * 4;
+      if (cidx + 3 < ncell1) {
+        *reinterpret_cast<int4*>(start + cidx) = make_int4(s, s, s, s);
+      } else {
+        for (int u = 0; u < 4; ++u)
+          if (cidx + u < ncell1) start[cidx + u] = s;
+      }
+    }
+    if (t == 0) occ[bk] = 0;
+    return;
+  }
+  const bool inreg = e - s <= T * kBkPer;
+  PointRec me[kBkPer];
+  int rr[kBkPer];
+  if (inreg) {
+#pragma unroll
+    for (int k = 0; k < kBkPer; ++k) {
+      const int j = s + k * T + t;
+      me[k].key = -1;
+      if (j < e) me[k] = bucketed[j];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) cnt[k * T + t] = 0;
+  __syncthreads();
+  if (inreg) {
+#pragma unroll
+    for (int k = 0; k < kBkPer; ++k)
+      if (me[k].key >= 0) rr[k] = atomicAdd(&cnt[(me[k].key >> 3) & (CELLS - 1)], 1);
+  } else {
+    for (int j = s + t; j < e; j += T) rank_tmp[j] = atomicAdd(&cnt[(bucketed[j].key >> 3) & (CELLS - 1)], 1);
+  }
+  __syncthreads();
+  int32_t v[8], tot = 0, nocc = 0;
+  {
+    const int4 a = *reinterpret_cast<const int4*>(&cnt[8 * t]);
+    const int4 b = *reinterpret_cast<const int4*>(&cnt[8 * t + 4]);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+    v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      tot += v[k];
+      nocc += v[k] > 0;
+    }
+  }
+  const int lane = t & 63, w = t >> 6;
+  int32_t incl = tot;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int32_t u = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += u;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) nocc += __shfl_down(nocc, off, 64);
+  if (lane == 63) wsum[w] = incl;
+  if (lane == 0) wocc[w] = nocc;
+  __syncthreads();
+  int32_t run = incl - tot;
+  for (int q = 0; q < w; ++q) run += wsum[q];
+  if (t == 0) {
+    int o = 0;
+    for (int q = 0; q < T / 64; ++q) o += wocc[q];
+    occ[bk] = o;
+  }
+  int32_t pre[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    pre[k] = run;
+    run += v[k];
+  }
+  {
+    const int64_t cidx = c0 + 8 * t;
+    if (cidx + 7 < ncell1) {
+      *reinterpret_cast<int4*>(start + cidx) = make_int4(s + pre[0], s + pre[1], s + pre[2], s + pre[3]);
+      *reinterpret_cast<int4*>(start + cidx + 4) = make_int4(s + pre[4], s + pre[5], s + pre[6], s + pre[7]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (cidx + k < ncell1) start[cidx + k] = s + pre[k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) cnt[8 * t + k] = pre[k];
+  __syncthreads();
+  auto place = [&](const PointRec& p, int arrival) {
+    const int f = s + cnt[(p.key >> 3) & (CELLS - 1)] + arrival;
+    order[f] = p.idx;
+    cell_of[f] = p.key >> 3;
+    sx[f] = p.x;
+    sy[f] = p.y;
+    sz[f] = p.z;
+  };
+  if (inreg) {
+#pragma unroll
+    for (int k = 0; k < kBkPer; ++k)
+      if (me[k].key >= 0) place(me[k], rr[k]);
+  } else {
+    for (int j = s + t; j < e; j += T) place(bucketed[j], rank_tmp[j]);
+  }
+}
+
+// build_grid through the two-level sort; returns false (nothing launched) when the directory has
+// more buckets than the A passes' LDS histogram holds or PYQSM_GRID_BIN=atomic asks for the
+// one-atomic-per-point path.
+static int build_grid_bucketed(Ctx* c, const double* xyz, int64_t n, DevGrid* g, bool* done) {
+  *done = false;
+  const int bits = g->ncell + 1 <= (int64_t(kBkMax) << 12) ? 12 : 13;
+  const int64_t nbk = (g->ncell + (int64_t(1) << bits)) >> bits;
+  const char* env = getenv("PYQSM_GRID_BIN");
+  if (nbk > kBkMax || (env && !strcmp(env, "atomic"))) return 0;
+  int32_t *tot, *bstart, *cursor, *key_tmp, *rank_tmp;
+  PointRec* bucketed;
+  PQ_TRY(c->arena.get(size_t(nbk), &tot));
+  PQ_TRY(c->arena.get(size_t(nbk) + 1, &bstart));
+  PQ_TRY(c->arena.get(size_t(nbk), &cursor));
+  PQ_TRY(c->arena.get(size_t(n), &key_tmp));
+  PQ_TRY(c->arena.get(size_t(n), &rank_tmp));
+  PQ_TRY(c->arena.get(size_t(n), &bucketed));
+  g->occ_blocks = int(nbk);
+  PQ_TRY(c->arena.get(size_t(nbk), &g->occ_part));
+  PQ_HIP(hipMemsetAsync(tot, 0, size_t(nbk) * 4, c->stream));
+  GridParams gp{g->minx, g->miny, g->minz, g->inv_cell, g->nx, g->ny, g->nz};
+  const dim3 ga(ceil_div(n, kBkPts)), blk(256);
+  const size_t lds = size_t(nbk) * 4;
+  hipLaunchKernelGGL(k_bk_hist<2>, ga, blk, lds, c->stream, xyz, n, gp, 0, 0, 0, AxisMap{nullptr, nullptr, nullptr},
+                     int(nbk), bits, key_tmp, tot);
+  hipLaunchKernelGGL(k_bk_scan, dim3(1), dim3(1024), 0, c->stream, int(nbk), tot, bstart, cursor);
+  hipLaunchKernelGGL(k_bk_scatter, ga, blk, lds, c->stream, xyz, n, int(nbk), bits, key_tmp, cursor, bucketed);
+  if (bits == 12)
+    hipLaunchKernelGGL(k_bk_sort_plain<12>, dim3(unsigned(nbk)), dim3(512), 0, c->stream, g->ncell + 1, bstart,
+                       bucketed, rank_tmp, g->start, g->order, g->cell_of, g->sx, g->sy, g->sz, g->occ_part);
+  else
+    hipLaunchKernelGGL(k_bk_sort_plain<13>, dim3(unsigned(nbk)), dim3(1024), 0, c->stream, g->ncell + 1, bstart,
+                       bucketed, rank_tmp, g->start, g->order, g->cell_of, g->sx, g->sy, g->sz, g->occ_part);
+  PQ_HIP(hipGetLastError());
+  *done = true;
+  return 0;
+}
+
 int build_grid_octants(Ctx* c, const double* xyz, int64_t n, double min_cell, int64_t max_cells,
                        DevGrid* g, SubCells* sub) {
   if (n <= 0) return fail(PYQSM_EINVAL, "build_grid_octants: empty cloud");
@@ -1177,10 +1350,10 @@ int build_grid_octants(Ctx* c, const double* xyz, int64_t n, double min_cell, in
     const dim3 ga(ceil_div(n, kBkPts));
     const size_t lds = size_t(nbk) * 4;
     if (mapped)
-      hipLaunchKernelGGL(k_bk_hist<true>, ga, blk, lds, c->stream, xyz, n, gp, raw[0], raw[1], raw[2], am,
+      hipLaunchKernelGGL(k_bk_hist<1>, ga, blk, lds, c->stream, xyz, n, gp, raw[0], raw[1], raw[2], am,
                          int(nbk), bits, cell_tmp, tot);
     else
-      hipLaunchKernelGGL(k_bk_hist<false>, ga, blk, lds, c->stream, xyz, n, gp, raw[0], raw[1], raw[2], am,
+      hipLaunchKernelGGL(k_bk_hist<0>, ga, blk, lds, c->stream, xyz, n, gp, raw[0], raw[1], raw[2], am,
                          int(nbk), bits, cell_tmp, tot);
     hipLaunchKernelGGL(k_bk_scan, dim3(1), dim3(1024), 0, c->stream, int(nbk), tot, bstart, cursor);
     hipLaunchKernelGGL(k_bk_scatter, ga, blk, lds, c->stream, xyz, n, int(nbk), bits, cell_tmp, cursor,
