@@ -132,22 +132,23 @@ def main():
     labels = d_lab.download((n,), np.int64)
     n_clusters = int(labels.max() + 1)
     value = world * n * args.steps / elapsed / 1e6
-    # the three neighbourhood kernels are timed individually (HIP events on the library
-    # stream around the single launch); the phases above contain several small kernels each
+    # The neighbourhood kernels are timed individually (HIP events on the library stream around the
+    # single launch); the phases above contain several small kernels each.
     dom = max(("k_core_tiled", "k_hook_sub", "k_union_sub"), key=lambda k: kernels[k]["avg_ms"])
     dom_ms = kernels[dom]["avg_ms"]
-    achieved = DBSCAN_BYTES_PER_POINT * n / (dom_ms * 1e-3) / 1e9
-    traffic, traffic_note = None, "no PMC summary found under profiles/"
-    tpath = os.path.join(ROOT, "profiles", "r02_dbscan_traffic.json")
-    if not os.path.exists(tpath):
-        tpath = os.path.join(ROOT, "profiles", "r01_dbscan_traffic.json")
-    if os.path.exists(tpath):                        # written from the rocprofv3 --pmc passes
+    step_ms = elapsed / args.steps * 1e3
+    # HBM bytes by the counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same section,
+    # profiles/r03_traffic.json; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)
+    tj = {}
+    tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")
+    if os.path.exists(tpath):
         with open(tpath) as f:
             tj = json.load(f)
-        if dom in tj.get("kernels", {}) and tj.get("points") == n:
-            traffic = tj["kernels"][dom]["hbm_bytes_per_launch"]
-            traffic_note = tj.get("note", "")
-    step_ms = elapsed / args.steps * 1e3
+    dbt = tj.get("dbscan", {}) if tj.get("points") == n else {}
+    step_bytes = dbt.get("hbm_bytes_per_unit")
+    kern_traffic = {q: {"hbm_bytes_per_launch": v["hbm_bytes_per_launch"], "launches_per_step": v["launches_per_unit"]}
+                    for q, v in dbt.get("kernels", {}).items()}
+    dom_bytes = kern_traffic.get(dom, {}).get("hbm_bytes_per_launch")
     # executed fp64 pair tests of the core pass (profiling level 2 adds a counter; one extra,
     # untimed call) priced against the FP64 vector peak: SURVEY.md §8d names FP64 VALU as the
     # binding roof of the neighbourhood kernels (8 flop + 1 compare per candidate pair)
@@ -155,27 +156,62 @@ def main():
     hip.prof_reset(dev)
     hip.dbscan_dev(d_xyz.ptr, n, eps, min_pts, d_lab.ptr, d_core.ptr, dev)
     _, lane_tests = hip.prof_get("core_pair_tests", dev)
+    _, f32_records = hip.prof_get("dbscan_f32_records", dev)
     hip.prof_enable(False, dev)
     core_ms = kernels["k_core_tiled"]["avg_ms"]
     core_tflops = 9.0 * lane_tests / (core_ms * 1e-3) / 1e12 if core_ms > 0 else 0.0
-    roofline = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "avg_launch_ms": dom_ms,
-                "traffic_GBs": (traffic / (dom_ms * 1e-3) / 1e9) if traffic else None,
-                "step_hbm_frac": DBSCAN_BYTES_PER_POINT * n / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "fp64_valu": {"kernel": "k_core_tiled", "lane_tests_per_launch": lane_tests,
-                              "flop_per_test": 9, "achieved": core_tflops, "peak": FP64_PEAK_TFLOPS,
-                              "unit": "TFLOP/s", "frac": core_tflops / FP64_PEAK_TFLOPS,
-                              "avg_launch_ms": core_ms,
-                              "note": "lane-tests EXECUTED (64 lanes x candidates staged per wave, "
-                                      "counted on the device at profiling level 2), early exits "
-                                      "included; SURVEY's stencil holds ~855 candidates per point"},
-                "note": "algorithmic bytes = 341 B/point (SURVEY.md §8d) x points per launch; "
-                        "the neighbour kernels are FP64-VALU/latency bound, not HBM bound "
-                        "(fp64_valu prices the core pass against the vector peak, step_hbm_frac "
-                        "the whole step against HBM, traffic_GBs = counter bytes / launch time). "
-                        "traffic: " + traffic_note}
+    achieved = step_bytes / (step_ms * 1e-3) / 1e9 if step_bytes else None
+    alg_step = DBSCAN_BYTES_PER_POINT * n / (step_ms * 1e-3) / 1e9
+    roofline = {
+        "kernel": "dbscan step (every kernel of one clustering)", "bound": "hbm",
+        "achieved": achieved if achieved is not None else alg_step, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": (achieved if achieved is not None else alg_step) / HBM_PEAK_GBS,
+        "traffic": step_bytes, "avg_launch_ms": step_ms,
+        "step_hbm_frac": alg_step / HBM_PEAK_GBS,
+        "algorithmic_bytes_per_step": DBSCAN_BYTES_PER_POINT * n,
+        "dominant_kernel": {"kernel": dom, "avg_launch_ms": dom_ms, "traffic": dom_bytes,
+                            "traffic_GBs": dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_bytes else None,
+                            "frac": dom_bytes / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if dom_bytes else None},
+        "per_kernel": {q: dict(v, avg_launch_ms=kernels[q]["avg_ms"],
+                               GBs=v["hbm_bytes_per_launch"] / (kernels[q]["avg_ms"] * 1e-3) / 1e9)
+                       for q, v in kern_traffic.items() if q in kernels and kernels[q]["avg_ms"] > 0},
+        "fp64_valu": {"kernel": "k_core_tiled", "lane_tests_per_launch": lane_tests,
+                      "flop_per_test": 9, "achieved": core_tflops, "peak": FP64_PEAK_TFLOPS,
+                      "unit": "TFLOP/s", "frac": core_tflops / FP64_PEAK_TFLOPS,
+                      "avg_launch_ms": core_ms,
+                      "note": "lane-tests EXECUTED (64 lanes x candidates staged per wave, "
+                              "counted on the device at profiling level 2), early exits "
+                              "included; SURVEY's stencil holds ~855 candidates per point"},
+        "fp32_records": bool(f32_records),
+        "note": "achieved = HBM bytes of ONE WHOLE STEP by the counters (sum over its ~20 kernels of 2 x FETCH_SIZE + "
+                "WRITE_SIZE per launch x launches per step, profiles/r03_traffic.json) / the step's time, live; frac = "
+                "that / 8 TB/s. step_hbm_frac prices the same step at SURVEY.md §8d's algorithmic 341 B/point instead. "
+                "The neighbourhood kernels are FP64-VALU / gather-latency bound, not HBM bound: fp64_valu prices the "
+                "core pass against the vector peak; dominant_kernel gives the slowest kernel's own counter bytes over "
+                "its own HIP-event time. " + ("" if step_bytes else "NO PMC summary for this size: achieved falls "
+                                              "back to the algorithmic figure and traffic is null.")}
 
+    # ---- binning class (passes x N x bytes; state the pass count)
+    ext = pts.max(0) - pts.min(0)
+    cell = eps * (1.0 + 1.0 / 1048576.0)
+    ncell = float(np.prod(np.floor(ext / cell) + 3.0))
+    rec_b = 28.0 if f32_records else 36.0           # sorted record: fp32 x,y,z,flag or three fp64 + order, cell, sub-cell
+    bin_alg = n * (24.0 + (24.0 + 4.0) + (24.0 + 4.0 + 32.0) + (32.0 + rec_b)) + 4.0 * ncell + 128.0 * (n / 5.0)
+    bin_ms = kernels["dbscan_bin"]["avg_ms"]
+    bin_names = ("k_bbox", "k_bbox_fold", "k_bk_hist", "k_bk_scan", "k_bk_scatter", "k_bk_sort", "k_order_big")
+    bin_bytes = sum(kern_traffic[q]["hbm_bytes_per_launch"] * kern_traffic[q]["launches_per_step"]
+                    for q in bin_names if q in kern_traffic) or None
+    binning = {"roofline": {
+        "kernel": "dbscan_bin: k_bbox, k_bk_hist, k_bk_scatter, k_bk_sort (+ 3 small kernels)", "bound": "hbm",
+        "passes_over_the_points": 4, "avg_launch_ms": bin_ms,
+        "algorithmic_bytes": bin_alg, "achieved": bin_alg / (bin_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+        "unit": "GB/s", "frac": bin_alg / (bin_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": bin_bytes,
+        "traffic_over_algorithmic": bin_bytes / bin_alg if bin_bytes else None,
+        "note": "four passes over the points: bounding box (24 B read), bucket histogram (24 read + 4 written), "
+                "bucket scatter (28 read + 32 written), in-LDS sort of every bucket (32 read + the sorted record "
+                f"written: {rec_b:.0f} B) = {24 + 28 + 60 + 32 + rec_b:.0f} B per point, plus the dense cell directory "
+                f"written once (4 B x {ncell:.3g} cells) and 128 B of sub-cell records per occupied cell (~n / 5 cells); the phase "
+                "also holds one host round trip (the bounding box sizes the grid)"}}
     out = {
         "metric": "Mpoints/s DBSCAN (1M-pt synthetic forest, eps=0.1, min_neighbors=10)",
         "value": value, "unit": "Mpoints/s", "n_gpus": world, "steps": args.steps,
@@ -185,7 +221,7 @@ def main():
         "config": {"workload": f"{n}-point synthetic tree cloud (configs[1]), DBSCAN eps=0.1 "
                                f"min_neighbors=10, {n_clusters} clusters; replicas at N>1",
                    "points_per_gpu": n, "parallelism": f"replicas x{world}"},
-        "roofline": roofline, "kernels": kernels,
+        "roofline": roofline, "binning": binning, "kernels": kernels,
     }
 
     # ------------------------------------------------------------- kNN (same cloud)
@@ -206,19 +242,26 @@ def main():
         kk = {name: hip.prof_get(name, dev) for name in ("knn_bin", "knn_search", "knn_retry")}
         hip.prof_enable(False, dev)
         search_ms = kk["knn_search"][0] / max(kk["knn_search"][1], 1)
+        knn_t = tj.get("knn", {}) if tj.get("points") == n else {}
         knn_bytes = (DBSCAN_BYTES_PER_POINT + 12.0 * k) * n      # stencil re-reads + idx/d2 rows out
         out["knn"] = {"k": k, "points_per_gpu": n, "steps": reps, "ms_per_step": dt / reps * 1e3,
                       "value": world * n / (dt / reps) / 1e6, "unit": "Mpoints/s", "dtype": "f64",
                       "phases_ms": {name: v[0] / reps for name, v in kk.items()},
-                      "roofline": {"kernel": "k_knn_reg<20> (knn_search)", "bound": "hbm",
+                      "roofline": {"kernel": "k_knn_reg<20> (knn_search)", "bound": "fp64-valu issue / gather latency",
                                    "achieved": knn_bytes / (search_ms * 1e-3) / 1e9,
                                    "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": knn_bytes / (search_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                   "traffic": None, "avg_launch_ms": search_ms,
-                                   "note": "algorithmic bytes = 341 B/point (SURVEY.md §8d, binned "
-                                           "neighbour class) + 12 B x k of result rows; the kernel is "
-                                           "bound by its per-candidate register insertion (FP64 VALU "
-                                           "issue), not by HBM"}}
+                                   "traffic": knn_t.get("kernels", {}).get("k_knn_reg", {}).get("hbm_bytes_per_launch"),
+                                   "avg_launch_ms": search_ms,
+                                   "valu_busy": knn_t.get("valu_busy"),
+                                   "wait_any": knn_t.get("wait_any"), "wait_inst_any": knn_t.get("wait_inst_any"),
+                                   "note": "achieved / frac price the search kernel at 341 B/point (SURVEY.md §8d, binned "
+                                           "neighbour class) + 12 B x k of result rows against HBM, which is NOT its "
+                                           "roof: valu_busy = SQ_ACTIVE_INST_VALU x 4 / 1024 SIMDs / (launch time x "
+                                           "2.4 GHz) says how much of the launch the vector pipes were issuing "
+                                           "(profiles/r03_knn_sq_counters.csv); wait_any / wait_inst_any = share of "
+                                           "wave cycles parked on memory / stalled at issue; traffic = counter bytes "
+                                           "per launch (profiles/r03_traffic.json)"}}
         if world == 1:
             # the same cloud with twenty stray returns 3-10 cloud sizes away (what terrestrial scans carry):
             # grids over the box without its tails + whole-cloud search of the strays
@@ -368,6 +411,7 @@ def main():
                 "outer_cg_steps": prof["lbc_outer_iter"][1],
                 "multigrid_cg_iterations": prof["lbc_amg_iter"][1],
                 "ms_per_multigrid_cg_iteration": prof["lbc_amg_iter"][0] / max(prof["lbc_amg_iter"][1], 1),
+                "iterations_per_solve": [int(q["iters"]) for q in log],
                 "solves_not_converged": sum(1 for q in log if not q["ok"]),
                 "max_true_residual": max((max(q["resid"]) for q in log), default=0.0),
                 "mean_shift_m": float(np.linalg.norm(total_shift, axis=1).mean())}
@@ -400,17 +444,49 @@ def main():
                              "frac": pass_bytes / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS if avg > 0 else 0.0}
         hip.prof_enable(False, dev)
         domk = max(passes, key=lambda q: passes[q]["avg_launch_ms"])
+        sol_t = (tj.get("solve", {}) if tj.get("points") == n else {}).get("kernels", {})
+        pmc_name = {"k_bspmv_f": "k_bspmv_f", "k_down_l0": "k_down", "k_up_l0": "k_up_ap"}
+        for kname, v in passes.items():
+            v["traffic"] = sol_t.get(pmc_name[kname], {}).get("hbm_bytes_per_launch")
+            v["traffic_over_algorithmic"] = v["traffic"] / pass_bytes if v["traffic"] else None
+        # the Laplacian build (SURVEY.md §8d "mixed" row: kNN part FP64 VALU, assembly HBM):
+        # N*(24 + 4k) bytes in, 12*nnz + 12*N out, against what the counters say it moves
+        lap_t = tj.get("laplacian", {}) if tj.get("points") == n else {}
+        row3 = rows["init_contraction_3"]
+        lap_ms = row3["laplacian_ms_per_build"]
+        lap_alg = n * (24.0 + 4.0 * 20) + 12.0 * L0.nnz + 12.0 * n
+        lap_bytes = lap_t.get("hbm_bytes_per_unit")
+        lap_kernels = lap_t.get("kernel_ms_per_unit", {})
+        top = sorted(lap_kernels.items(), key=lambda kv: -kv[1])[:10]
+        lap_roof = {
+            "kernel": "one point-cloud Laplacian build (lap_knn + lap_fans + lap_assemble)", "bound": "mixed (SURVEY.md §8d)",
+            "avg_launch_ms": lap_ms, "algorithmic_bytes": lap_alg,
+            "achieved": lap_alg / (lap_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": lap_alg / (lap_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "traffic": lap_bytes, "traffic_GBs": lap_bytes / (lap_ms * 1e-3) / 1e9 if lap_bytes else None,
+            "traffic_frac": lap_bytes / (lap_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if lap_bytes else None,
+            "traffic_over_algorithmic": lap_bytes / lap_alg if lap_bytes else None,
+            "kernel_ms_per_build_top10": {q: round(v, 3) for q, v in top},
+            "note": "algorithmic bytes = N*(24 + 4k) in + 12*nnz + 12*N out (SURVEY.md §8d); traffic = counter bytes "
+                    "of one build on the raw cloud (profiles/r03_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE summed over "
+                    "its ~60 kernels); the build is not a streaming pass: the intrinsic Delaunay flips (~50 scattered "
+                    "accesses per flip, rounds of conflict-free flips) and the per-point fan construction (a 3x3 Jacobi "
+                    "eigen-decomposition and k^2 empty-circle tests per point, FP64 VALU) bound it, so its HBM fraction "
+                    "says how far from a pure assembly it is, not how well it streams"}
         out["skeleton"] = {
             "workload": f"{n}-point forest, extract_skeleton with max_iter={args.skel_iters}, "
                         "termination_ratio=0 (configs[2]), TOML weights; wall of the call incl. PCIe in and out",
             "rows": rows, "dtype": "f64 (multigrid preconditioner in f32)",
             "roofline": {"kernel": domk, "bound": "hbm", "achieved": passes[domk]["achieved"],
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": passes[domk]["frac"],
-                         "traffic": None, "passes": passes, "nnz": int(L0.nnz),
+                         "traffic": passes[domk]["traffic"], "passes": passes, "nnz": int(L0.nnz),
                          "note": "level-0 sparse passes (fp32 values, 3 right-hand sides as float4 rows) "
                                  "priced at 8*nnz + 36*N algorithmic bytes each; HIP events around single "
                                  "launches (profiling level 2) over all contractions (the first two alone: "
-                                 "37-38 us per pass, before the cloud has collapsed onto its skeleton)"}}
+                                 "37-38 us per pass, before the cloud has collapsed onto its skeleton); traffic = "
+                                 "counter bytes per level-0 launch in the first contraction solve "
+                                 "(profiles/r03_traffic.json)"},
+            "laplacian_build": {"roofline": lap_roof}}
         if rank == 0 and not args.no_cpu:
             # the reference's own solve (three SciPy spsolve calls, skeletonize.py:167-173) on
             # bounded samples: the first contraction of a 30 k- and a 100 k-point forest
