@@ -357,10 +357,11 @@ int cloud_bbox(Ctx* c, const double* xyz, int64_t n, double mn[3], double mx[3],
   return 0;
 }
 
-static int build_grid_bucketed(Ctx* c, const double* xyz, int64_t n, DevGrid* g, bool* done);
+static int build_grid_bucketed(Ctx* c, const double* xyz, int64_t n, DevGrid* g);
+static bool bucketed_fits(const DevGrid& g);
 
 int build_grid(Ctx* c, const double* xyz, int64_t n, double min_cell, int64_t max_cells,
-               DevGrid* g, const double* bbox) {
+               DevGrid* g, const double* bbox, bool f32_records) {
   if (n <= 0) return fail(PYQSM_EINVAL, "build_grid: empty cloud");
   if (n > 0x7FFFFF00LL) return fail(PYQSM_ERANGE, "more than 2^31 points per call");
   if (!(min_cell > 0) || !std::isfinite(min_cell))
@@ -401,15 +402,24 @@ int build_grid(Ctx* c, const double* xyz, int64_t n, double min_cell, int64_t ma
   PQ_TRY(c->arena.get(size_t(g->ncell) + 1, &g->start));
   PQ_TRY(c->arena.get(size_t(n), &g->order));
   PQ_TRY(c->arena.get(size_t(n), &g->cell_of));
-  PQ_TRY(c->arena.get(size_t(n), &g->sx));
-  PQ_TRY(c->arena.get(size_t(n), &g->sy));
-  PQ_TRY(c->arena.get(size_t(n), &g->sz));
+  // two-level counting sort: no scattered atomics, no memset and no scan of the directory; with
+  // it, fp32 records instead of three fp64 arrays when the caller vouches for the input
+  // (cloud_bbox's flag) and reads through on_coords()
+  const bool bucketed = bucketed_fits(*g);
   g->p4 = nullptr;
-  {  // two-level counting sort: no scattered atomics, no memset and no scan of the directory
-    bool done = false;
-    PQ_TRY(build_grid_bucketed(c, xyz, n, g, &done));
-    if (done) return 0;
+  g->sx = g->sy = g->sz = nullptr;
+  {
+    const char* f32_env = getenv("PYQSM_COORD_F32");  // "0": keep fp64 storage (A/B comparisons)
+    if (f32_env && !strcmp(f32_env, "0")) f32_records = false;
   }
+  if (bucketed && f32_records) {
+    PQ_TRY(c->arena.get(size_t(n), &g->p4));
+  } else {
+    PQ_TRY(c->arena.get(size_t(n), &g->sx));
+    PQ_TRY(c->arena.get(size_t(n), &g->sy));
+    PQ_TRY(c->arena.get(size_t(n), &g->sz));
+  }
+  if (bucketed) return build_grid_bucketed(c, xyz, n, g);
   PQ_TRY(c->arena.get(size_t(n), &cell_tmp));
   PQ_TRY(c->arena.get(size_t(n), &rank_tmp));
   PQ_HIP(hipMemsetAsync(g->start, 0, (size_t(g->ncell) + 1) * 4, c->stream));
@@ -1080,7 +1090,7 @@ __global__ __launch_bounds__((1 << BITS) / 8) void k_bk_sort_plain(
     int64_t ncell1, const int32_t* __restrict__ bstart, const PointRec* __restrict__ bucketed,
     int32_t* __restrict__ rank_tmp, int32_t* __restrict__ start, int32_t* __restrict__ order,
     int32_t* __restrict__ cell_of, double* __restrict__ sx, double* __restrict__ sy, double* __restrict__ sz,
-    int32_t* __restrict__ occ) {
+    float4* __restrict__ p4 /*non-null: fp32 records instead of sx / sy / sz*/, int32_t* __restrict__ occ) {
   constexpr int CELLS = 1 << BITS, T = CELLS / 8;
   __shared__ int32_t cnt[CELLS];
   __shared__ int32_t wsum[16], wocc[16];
@@ -1178,9 +1188,13 @@ __global__ __launch_bounds__((1 << BITS) / 8) void k_bk_sort_plain(
     const int f = s + cnt[(p.key >> 3) & (CELLS - 1)] + arrival;
     order[f] = p.idx;
     cell_of[f] = p.key >> 3;
-    sx[f] = p.x;
-    sy[f] = p.y;
-    sz[f] = p.z;
+    if (p4) {
+      p4[f] = make_float4(float(p.x), float(p.y), float(p.z), 0.f);
+    } else {
+      sx[f] = p.x;
+      sy[f] = p.y;
+      sz[f] = p.z;
+    }
   };
   if (inreg) {
 #pragma unroll
@@ -1194,12 +1208,16 @@ __global__ __launch_bounds__((1 << BITS) / 8) void k_bk_sort_plain(
 // build_grid through the two-level sort; returns false (nothing launched) when the directory has
 // more buckets than the A passes' LDS histogram holds or PYQSM_GRID_BIN=atomic asks for the
 // one-atomic-per-point path.
-static int build_grid_bucketed(Ctx* c, const double* xyz, int64_t n, DevGrid* g, bool* done) {
-  *done = false;
+static bool bucketed_fits(const DevGrid& g) {
+  const int bits = g.ncell + 1 <= (int64_t(kBkMax) << 12) ? 12 : 13;
+  const int64_t nbk = (g.ncell + (int64_t(1) << bits)) >> bits;
+  const char* env = getenv("PYQSM_GRID_BIN");
+  return nbk <= kBkMax && !(env && !strcmp(env, "atomic"));
+}
+
+static int build_grid_bucketed(Ctx* c, const double* xyz, int64_t n, DevGrid* g) {
   const int bits = g->ncell + 1 <= (int64_t(kBkMax) << 12) ? 12 : 13;
   const int64_t nbk = (g->ncell + (int64_t(1) << bits)) >> bits;
-  const char* env = getenv("PYQSM_GRID_BIN");
-  if (nbk > kBkMax || (env && !strcmp(env, "atomic"))) return 0;
   int32_t *tot, *bstart, *cursor, *key_tmp, *rank_tmp;
   PointRec* bucketed;
   PQ_TRY(c->arena.get(size_t(nbk), &tot));
@@ -1220,12 +1238,11 @@ static int build_grid_bucketed(Ctx* c, const double* xyz, int64_t n, DevGrid* g,
   hipLaunchKernelGGL(k_bk_scatter, ga, blk, lds, c->stream, xyz, n, int(nbk), bits, key_tmp, cursor, bucketed);
   if (bits == 12)
     hipLaunchKernelGGL(k_bk_sort_plain<12>, dim3(unsigned(nbk)), dim3(512), 0, c->stream, g->ncell + 1, bstart,
-                       bucketed, rank_tmp, g->start, g->order, g->cell_of, g->sx, g->sy, g->sz, g->occ_part);
+                       bucketed, rank_tmp, g->start, g->order, g->cell_of, g->sx, g->sy, g->sz, g->p4, g->occ_part);
   else
     hipLaunchKernelGGL(k_bk_sort_plain<13>, dim3(unsigned(nbk)), dim3(1024), 0, c->stream, g->ncell + 1, bstart,
-                       bucketed, rank_tmp, g->start, g->order, g->cell_of, g->sx, g->sy, g->sz, g->occ_part);
+                       bucketed, rank_tmp, g->start, g->order, g->cell_of, g->sx, g->sy, g->sz, g->p4, g->occ_part);
   PQ_HIP(hipGetLastError());
-  *done = true;
   return 0;
 }
 
@@ -1467,11 +1484,12 @@ __global__ __launch_bounds__(256) void k_pyr_scatter(int n, Pyr P, const int32_t
                                                      const double* __restrict__ fx,
                                                      const double* __restrict__ fy,
                                                      const double* __restrict__ fz,
+                                                     const float4* __restrict__ fp4,
                                                      int32_t* __restrict__ order,
                                                      int32_t* __restrict__ cell_of,
                                                      double* __restrict__ sx,
                                                      double* __restrict__ sy,
-                                                     double* __restrict__ sz) {
+                                                     double* __restrict__ sz, float4* __restrict__ p4) {
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= n) return;
   const int f = f_cell_of[p];
@@ -1479,9 +1497,13 @@ __global__ __launch_bounds__(256) void k_pyr_scatter(int n, Pyr P, const int32_t
   const int q = cstart[C] + foff[f] + (p - fstart[f]);
   order[q] = f_order[p];
   cell_of[q] = C;
-  sx[q] = fx[p];
-  sy[q] = fy[p];
-  sz[q] = fz[p];
+  if (fp4) {
+    p4[q] = fp4[p];
+  } else {
+    sx[q] = fx[p];
+    sy[q] = fy[p];
+    sz[q] = fz[p];
+  }
 }
 
 int coarsen_grid(Ctx* c, const DevGrid& fine, int64_t n, int factor, DevGrid* g) {
@@ -1508,9 +1530,13 @@ int coarsen_grid(Ctx* c, const DevGrid& fine, int64_t n, int factor, DevGrid* g)
   PQ_TRY(c->arena.get(size_t(g->ncell) + 1, &g->start));
   PQ_TRY(c->arena.get(size_t(n), &g->order));
   PQ_TRY(c->arena.get(size_t(n), &g->cell_of));
-  PQ_TRY(c->arena.get(size_t(n), &g->sx));
-  PQ_TRY(c->arena.get(size_t(n), &g->sy));
-  PQ_TRY(c->arena.get(size_t(n), &g->sz));
+  if (fine.p4) {
+    PQ_TRY(c->arena.get(size_t(n), &g->p4));
+  } else {
+    PQ_TRY(c->arena.get(size_t(n), &g->sx));
+    PQ_TRY(c->arena.get(size_t(n), &g->sy));
+    PQ_TRY(c->arena.get(size_t(n), &g->sz));
+  }
   PQ_HIP(hipMemsetAsync(g->start + g->ncell, 0, 4, c->stream));
   hipLaunchKernelGGL(k_pyr_counts, dim3(ceil_div(g->ncell, 256)), dim3(256), 0, c->stream, P,
                      fine.start, g->start, foff);
@@ -1518,7 +1544,7 @@ int coarsen_grid(Ctx* c, const DevGrid& fine, int64_t n, int factor, DevGrid* g)
   PQ_TRY(exclusive_scan_i32(c, g->start, g->ncell + 1));
   hipLaunchKernelGGL(k_pyr_scatter, dim3(ceil_div(n, 256)), dim3(256), 0, c->stream, int(n), P,
                      fine.start, g->start, foff, fine.cell_of, fine.order, fine.sx, fine.sy, fine.sz,
-                     g->order, g->cell_of, g->sx, g->sy, g->sz);
+                     static_cast<const float4*>(fine.p4), g->order, g->cell_of, g->sx, g->sy, g->sz, g->p4);
   PQ_HIP(hipGetLastError());
   return 0;
 }

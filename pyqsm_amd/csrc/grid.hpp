@@ -38,9 +38,11 @@ struct DevGrid {
 // `max_cells` cells). All arrays come from the context arena. Synchronises the
 // stream once (bounding box read-back). Fails with PYQSM_EINVAL on non-finite
 // coordinates.
-// `bbox` (min xyz, max xyz), when given, skips the bounding-box pass.
+// `bbox` (min xyz, max xyz), when given, skips the bounding-box pass. `f32_records`: the caller
+// knows (cloud_bbox) that every coordinate is fp32-representable and reads the grid through
+// on_coords(): the sorted points are then kept as g->p4 instead of g->sx / sy / sz.
 int build_grid(Ctx* c, const double* xyz, int64_t n, double min_cell, int64_t max_cells,
-               DevGrid* g, const double* bbox = nullptr);
+               DevGrid* g, const double* bbox = nullptr, bool f32_records = false);
 
 // Bounding box of the cloud (one reduction kernel, a one-block fold, a 56-byte read-back).
 // *all_f32 (optional): every coordinate is exactly representable in fp32. zero_buf / zero_n

@@ -57,15 +57,13 @@ struct KnnGrid {
 // sqdist3: grid.hpp
 
 // T = threads per block (LDS holds T columns of k (d2, id) pairs).
-template <int T>
+template <int T, class CO>
 __global__ __launch_bounds__(T) void k_knn(int n_query, const int32_t* __restrict__ query_list,
                                            const int32_t* __restrict__ pos_of /*orig->sorted*/,
                                            KnnGrid g, const int32_t* __restrict__ start,
                                            const int32_t* __restrict__ order,
                                            const int32_t* __restrict__ cell_of,
-                                           const double* __restrict__ sx,
-                                           const double* __restrict__ sy,
-                                           const double* __restrict__ sz, int k,
+                                           CO co, int k,
                                            int exclude_self, int n_total, int last_level,
                                            int32_t* __restrict__ out_idx,
                                            double* __restrict__ out_d2,
@@ -80,7 +78,8 @@ __global__ __launch_bounds__(T) void k_knn(int n_query, const int32_t* __restric
   // sorted position of this query
   const int p = query_list ? pos_of[query_list[qi]] : qi;
   const int self = order[p];
-  const double x = sx[p], y = sy[p], z = sz[p];
+  double x, y, z;
+  co.get(p, x, y, z);
   const int c = cell_of[p];
   const int cx = c % g.nx, cy = (c / g.nx) % g.ny, cz = c / (g.nx * g.ny);
   int have = 0;
@@ -111,7 +110,7 @@ __global__ __launch_bounds__(T) void k_knn(int n_query, const int32_t* __restric
           const int qb = start[row + x0], qe = start[row + x1 + 1];
           for (int q = qb; q < qe; ++q) {
             if (exclude_self && q == p) continue;
-            const double d = sqdist3(x, y, z, sx[q], sy[q], sz[q]);
+            const double d = co.d2(q, x, y, z);
             const int id = order[q];
             if (have == k) {
               const double wd = bd[(k - 1) * T + t];
@@ -171,7 +170,7 @@ __global__ __launch_bounds__(T) void k_knn(int n_query, const int32_t* __restric
 // `tie_list` and searched again by the exact variant (STRICT = false over `qlist`). Coordinates
 // quantised to millimetres give a few per cent of such queries, a regular lattice nearly all
 // (then the strict pass is wasted: 1.7x the exact kernel alone).
-template <int K, int BUF, bool STRICT>
+template <int K, int BUF, bool STRICT, class CO>
 __global__ __launch_bounds__(256) void k_knn_reg(int n_query, KnnGrid g,
                                                  const int32_t* __restrict__ qlist /*sorted positions
                                                  to search, or null: all n_query*/,
@@ -182,9 +181,7 @@ __global__ __launch_bounds__(256) void k_knn_reg(int n_query, KnnGrid g,
                                                  const int32_t* __restrict__ start,
                                                  const int32_t* __restrict__ order,
                                                  const int32_t* __restrict__ cell_of,
-                                                 const double* __restrict__ sx,
-                                                 const double* __restrict__ sy,
-                                                 const double* __restrict__ sz, int k,
+                                                 CO co, int k,
                                                  int exclude_self, int n_total, int last_level,
                                                  int32_t* __restrict__ out_idx,
                                                  double* __restrict__ out_d2,
@@ -202,7 +199,8 @@ __global__ __launch_bounds__(256) void k_knn_reg(int n_query, KnnGrid g,
     return;
   }
   const int self = order[p];
-  const double x = sx[p], y = sy[p], z = sz[p];
+  double x, y, z;
+  co.get(p, x, y, z);
   const int c = cell_of[p];
   const int cx = c % g.nx, cy = (c / g.nx) % g.ny, cz = c / (g.nx * g.ny);
   double bd[K];
@@ -298,7 +296,7 @@ __global__ __launch_bounds__(256) void k_knn_reg(int n_query, KnnGrid g,
           for (int q = qb; q < qe; ++q) {
             if constexpr (BUF > 0) {
               // no early `continue`: every lane that is in this iteration reaches the ballot
-              const double d = sqdist3(x, y, z, sx[q], sy[q], sz[q]);
+              const double d = co.d2(q, x, y, z);
               bool acc = !(exclude_self && q == p) && (d < bd[K - 1] || d == bd[K - 1]);
               int id = 0x7FFFFFFF;
               if (acc) {
@@ -319,7 +317,7 @@ __global__ __launch_bounds__(256) void k_knn_reg(int n_query, KnnGrid g,
               if (__ballot(nbuf == NB) != 0ull) flush();
             } else {
               if (exclude_self && q == p) continue;
-              const double d = sqdist3(x, y, z, sx[q], sy[q], sz[q]);
+              const double d = co.d2(q, x, y, z);
               if (!(d < bd[K - 1] || d == bd[K - 1])) continue;  // cheap reject before the id load
               const int id = order[q];
               if (!(d < bd[K - 1] || (d == bd[K - 1] && id < bi[K - 1]))) continue;
@@ -406,11 +404,11 @@ static int knn_buffer_slots() {  // PYQSM_KNN_BUF=0: direct insertion (the round
   return v;
 }
 
+template <class CO>
 __global__ void k_knn_wave(int n_query, const int32_t* __restrict__ n_ptr, int n_max,
                            const int32_t* __restrict__ query_list, const int32_t* __restrict__ pos_of,
                            KnnGrid g, const int32_t* __restrict__ start, const int32_t* __restrict__ order,
-                           const int32_t* __restrict__ cell_of, const double* __restrict__ sx,
-                           const double* __restrict__ sy, const double* __restrict__ sz, int k,
+                           const int32_t* __restrict__ cell_of, CO co, int k,
                            int exclude_self, int n_total, int last_level, int max_ring,
                            int32_t* __restrict__ out_idx, double* __restrict__ out_d2,
                            int32_t* __restrict__ fail_list, int32_t* __restrict__ fail_count);
@@ -431,34 +429,33 @@ static int launch_knn_reg(Ctx* c, int n, const DevGrid& g, int k, int excl, int 
   KnnGrid kg{g.nx, g.ny, g.nz, g.cell, g.minx, g.miny, g.minz};
   const dim3 grid(ceil_div(n, 256)), blk(256);
   const int32_t* none = nullptr;
-  if (knn_buffer_slots() == 0) {
-    hipLaunchKernelGGL((k_knn_reg<K, 0, false>), grid, blk, 0, c->stream, n, kg, none, none, 0, g.start, g.order,
-                       g.cell_of, g.sx, g.sy, g.sz, k, excl, n, last, idx, d2, fail_list, fail_count, tie_list,
-                       tie_count);
-  } else if (!knn_strict()) {
-    hipLaunchKernelGGL((k_knn_reg<K, 4, false>), grid, blk, 0, c->stream, n, kg, none, none, 0, g.start, g.order,
-                       g.cell_of, g.sx, g.sy, g.sz, k, excl, n, last, idx, d2, fail_list, fail_count, tie_list,
-                       tie_count);
-  } else {
-    hipLaunchKernelGGL((k_knn_reg<K, 4, true>), grid, blk, 0, c->stream, n, kg, none, none, 0, g.start, g.order,
-                       g.cell_of, g.sx, g.sy, g.sz, k, excl, n, last, idx, d2, fail_list, fail_count, tie_list,
-                       tie_count);
-    // The queries whose result hung on a tie, by the exact comparison: a WAVE per query (a lane per
-    // query would be one long-running wave of 64 unrelated walks — 0.5 ms for 238 such queries of
-    // a millimetre-quantised million points; this way they cost 20 us). Their number stays on the
-    // device; the waves of a fixed grid stride over them. A cloud on a regular lattice ties nearly
-    // everywhere (760 k of a million queries): past n / 16 the list goes to the per-lane kernel
-    // with the exact comparison instead (both launches are issued, one of them finds nothing to do).
-    const int many = n / 16;
-    hipLaunchKernelGGL(k_knn_wave, dim3(unsigned(std::min<int64_t>(ceil_div(n, 4), 8192))), blk, 0, c->stream, n,
-                       static_cast<const int32_t*>(tie_count), many, static_cast<const int32_t*>(tie_list),
-                       static_cast<const int32_t*>(nullptr), kg, g.start, g.order, g.cell_of, g.sx, g.sy, g.sz, k,
-                       excl, n, last, kMaxRing, idx, d2, fail_list, fail_count);
-    hipLaunchKernelGGL((k_knn_reg<K, 4, false>), grid, blk, 0, c->stream, n, kg,
-                       static_cast<const int32_t*>(tie_list), static_cast<const int32_t*>(tie_count), many,
-                       g.start, g.order, g.cell_of, g.sx, g.sy, g.sz, k, excl, n, last, idx, d2, fail_list,
-                       fail_count, tie_list, tie_count);
-  }
+  on_coords(g, [&](auto co) {
+    using CO = decltype(co);
+    if (knn_buffer_slots() == 0) {
+      hipLaunchKernelGGL((k_knn_reg<K, 0, false, CO>), grid, blk, 0, c->stream, n, kg, none, none, 0, g.start, g.order,
+                         g.cell_of, co, k, excl, n, last, idx, d2, fail_list, fail_count, tie_list, tie_count);
+    } else if (!knn_strict()) {
+      hipLaunchKernelGGL((k_knn_reg<K, 4, false, CO>), grid, blk, 0, c->stream, n, kg, none, none, 0, g.start, g.order,
+                         g.cell_of, co, k, excl, n, last, idx, d2, fail_list, fail_count, tie_list, tie_count);
+    } else {
+      hipLaunchKernelGGL((k_knn_reg<K, 4, true, CO>), grid, blk, 0, c->stream, n, kg, none, none, 0, g.start, g.order,
+                         g.cell_of, co, k, excl, n, last, idx, d2, fail_list, fail_count, tie_list, tie_count);
+      // The queries whose result hung on a tie, by the exact comparison: a WAVE per query (a lane per
+      // query would be one long-running wave of 64 unrelated walks — 0.5 ms for 238 such queries of
+      // a millimetre-quantised million points; this way they cost 20 us). Their number stays on the
+      // device; the waves of a fixed grid stride over them. A cloud on a regular lattice ties nearly
+      // everywhere (760 k of a million queries): past n / 16 the list goes to the per-lane kernel
+      // with the exact comparison instead (both launches are issued, one of them finds nothing to do).
+      const int many = n / 16;
+      hipLaunchKernelGGL(k_knn_wave<CO>, dim3(unsigned(std::min<int64_t>(ceil_div(n, 4), 8192))), blk, 0, c->stream, n,
+                         static_cast<const int32_t*>(tie_count), many, static_cast<const int32_t*>(tie_list),
+                         static_cast<const int32_t*>(nullptr), kg, g.start, g.order, g.cell_of, co, k, excl, n, last,
+                         kMaxRing, idx, d2, fail_list, fail_count);
+      hipLaunchKernelGGL((k_knn_reg<K, 4, false, CO>), grid, blk, 0, c->stream, n, kg,
+                         static_cast<const int32_t*>(tie_list), static_cast<const int32_t*>(tie_count), many, g.start,
+                         g.order, g.cell_of, co, k, excl, n, last, idx, d2, fail_list, fail_count, tie_list, tie_count);
+    }
+  });
   PQ_HIP(hipGetLastError());
   return 0;
 }
@@ -467,6 +464,7 @@ static int launch_knn_reg(Ctx* c, int n, const DevGrid& g, int k, int excl, int 
 // coarse and hold thousands of points, so the 64 lanes scan a run together.
 // The sorted best-k list lives in registers, element j in lane j; an insertion
 // is a ballot (position) plus one lane shift.
+template <class CO>
 __global__ __launch_bounds__(256) void k_knn_wave(int n_query,
                                                   const int32_t* __restrict__ n_ptr /*the number of
                                                   queries on the device, or null: n_query*/,
@@ -478,9 +476,7 @@ __global__ __launch_bounds__(256) void k_knn_wave(int n_query,
                                                   const int32_t* __restrict__ start,
                                                   const int32_t* __restrict__ order,
                                                   const int32_t* __restrict__ cell_of,
-                                                  const double* __restrict__ sx,
-                                                  const double* __restrict__ sy,
-                                                  const double* __restrict__ sz, int k,
+                                                  CO co, int k,
                                                   int exclude_self, int n_total, int last_level,
                                                   int max_ring, int32_t* __restrict__ out_idx,
                                                   double* __restrict__ out_d2,
@@ -493,7 +489,8 @@ __global__ __launch_bounds__(256) void k_knn_wave(int n_query,
   for (int qi = blockIdx.x * wpb + (threadIdx.x >> 6); qi < nq; qi += gridDim.x * wpb) {  // whole waves
   const int p = query_list ? (pos_of ? pos_of[query_list[qi]] : query_list[qi]) : qi;
   const int self = order[p];
-  const double x = sx[p], y = sy[p], z = sz[p];
+  double x, y, z;
+  co.get(p, x, y, z);
   const int c = cell_of[p];
   const int cx = c % g.nx, cy = (c / g.nx) % g.ny, cz = c / (g.nx * g.ny);
   double bd = __builtin_inf();
@@ -558,7 +555,7 @@ __global__ __launch_bounds__(256) void k_knn_wave(int n_query,
           double d = __builtin_inf();
           int id = 0x7FFFFFFF;
           if (valid) {
-            d = sqdist3(x, y, z, sx[q], sy[q], sz[q]);
+            d = co.d2(q, x, y, z);
             id = order[q];
           }
           const bool cand = valid && (have < k || d < tau_d || (d == tau_d && id < tau_i));
@@ -771,14 +768,18 @@ static int launch_knn(Ctx* c, int n_query, const int32_t* list, const int32_t* p
   static std::atomic<uint64_t> attr_set{0};  // one bit per device (the attribute is per device)
   const uint64_t bit = 1ull << (c->device & 63);
   if (!(attr_set.load(std::memory_order_acquire) & bit)) {
-    PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_knn<T>),
+    PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_knn<T, CoordsF64>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_knn<T, CoordsF32>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set.fetch_or(bit, std::memory_order_release);
   }
   KnnGrid kg{g.nx, g.ny, g.nz, g.cell, g.minx, g.miny, g.minz};
-  hipLaunchKernelGGL(k_knn<T>, dim3(ceil_div(n_query, T)), dim3(T), smem, c->stream, n_query, list,
-                     pos_of, kg, g.start, g.order, g.cell_of, g.sx, g.sy, g.sz, k, excl, n_total,
-                     last, idx, d2, fail_list, fail_count);
+  on_coords(g, [&](auto co) {
+    hipLaunchKernelGGL((k_knn<T, decltype(co)>), dim3(ceil_div(n_query, T)), dim3(T), smem, c->stream, n_query, list,
+                       pos_of, kg, g.start, g.order, g.cell_of, co, k, excl, n_total, last, idx, d2, fail_list,
+                       fail_count);
+  });
   PQ_HIP(hipGetLastError());
   return 0;
 }
@@ -796,9 +797,10 @@ int knn_device(Ctx* c, const double* xyz, int64_t n, int32_t k, int32_t exclude_
   DevGrid g;
   const int64_t max_cells = int64_t(1) << 28;
   double box[6];
+  bool all_f32 = false;  // every coordinate fp32-representable: the grids keep 16-byte fp32 records
   {
     ProfScope ps(c, "knn_bin");
-    PQ_TRY(cloud_bbox(c, xyz, n, box, box + 3));
+    PQ_TRY(cloud_bbox(c, xyz, n, box, box + 3, &all_f32));
     // grids over the cloud without its sparse tails; what is given up is what k_knn_brute can take
     const char* rbe = getenv("PYQSM_KNN_ROBUST_BOX");  // "0": grids over the full box
     const bool robust = !(rbe && rbe[0] == '0');
@@ -828,7 +830,7 @@ int knn_device(Ctx* c, const double* xyz, int64_t n, int32_t k, int32_t exclude_
     }
     cell = std::max(cell, ext / 4096.0);
     for (int it = 0; it < 2; ++it) {
-      PQ_TRY(build_grid(c, xyz, n, cell, max_cells, &g, box));
+      PQ_TRY(build_grid(c, xyz, n, cell, max_cells, &g, box, all_f32));
       if (it == 1) break;
       int64_t occ = 0;
       PQ_TRY(count_occupied(c, g, &occ));
@@ -875,9 +877,11 @@ int knn_device(Ctx* c, const double* xyz, int64_t n, int32_t k, int32_t exclude_
         KnnGrid kg{g.nx, g.ny, g.nz, g.cell, g.minx, g.miny, g.minz};
         // (one or two waves per block instead of four: no difference — the launch lasts as long as its
         // longest waves, 0.34 ms for the forest's 9 864 outliers)
-        hipLaunchKernelGGL(k_knn_wave, dim3(ceil_div(n_query, 4)), dim3(256), 0, c->stream, n_query,
-                           static_cast<const int32_t*>(nullptr), 0, list, pos_of, kg, g.start, g.order, g.cell_of, g.sx, g.sy, g.sz, k,
-                           exclude_self, N, last, ring, idx, d2, fl, fail_count);
+        on_coords(g, [&](auto co) {
+          hipLaunchKernelGGL(k_knn_wave<decltype(co)>, dim3(ceil_div(n_query, 4)), dim3(256), 0, c->stream, n_query,
+                             static_cast<const int32_t*>(nullptr), 0, list, pos_of, kg, g.start, g.order, g.cell_of, co,
+                             k, exclude_self, N, last, ring, idx, d2, fl, fail_count);
+        });
         PQ_HIP(hipGetLastError());
       } else if (k <= 48)
         PQ_TRY(launch_knn<256>(c, n_query, list, pos_of, g, k, exclude_self, N, last, idx, d2, fl,
@@ -931,7 +935,7 @@ int knn_device(Ctx* c, const double* xyz, int64_t n, int32_t k, int32_t exclude_
       // fine grids (the later levels) keep the pyramid: no atomics, a few microseconds.
       DevGrid coarse;
       if (g.ncell > (int64_t(1) << 22))
-        PQ_TRY(build_grid(c, xyz, n, g.cell * 4.0, max_cells, &coarse, box));
+        PQ_TRY(build_grid(c, xyz, n, g.cell * 4.0, max_cells, &coarse, box, all_f32));
       else
         PQ_TRY(coarsen_grid(c, g, n, 4, &coarse));
       g = coarse;
