@@ -25,6 +25,7 @@
 #include "common.hpp"
 #include "grid.hpp"
 
+#include <atomic>
 #include <chrono>
 #include <cmath>
 
@@ -367,6 +368,310 @@ __global__ __launch_bounds__(256) void k_fps_pruned(int s, int start_idx, int nb
   if (tid == 0) pnext[blockIdx.x] = mb;
 }
 
+// ---- the late rounds in ONE launch ------------------------------------------------------------
+// Once the samples' reach is down to a cell or two, a round touches a few dozen buckets: what it
+// costs as a launch (5.9 us) is the launch and three dependent round trips across the chip, 100 000
+// times. k_fps_tail runs all remaining rounds inside one workgroup — no grid barrier, nothing that
+// could wait for another block — with a second level over the buckets kept in LDS:
+//   the buckets are put into Morton order of their cells first (k_fps_tail_key / _prep), so that 64
+//   consecutive buckets are a compact blob; a GROUP of 64 keeps its bounding box and its (largest
+//   distance, lowest index, coordinates) in LDS. A round = the best of the group maxima (LDS, the
+//   sample's coordinates come with it: no look-up) -> the groups whose box is closer than their
+//   largest distance (LDS) -> their buckets' records and boxes, one gather, kept in LDS -> the few
+//   buckets the sample can improve are updated, a wave each, exactly as k_fps_pruned does it, the
+//   new record going to LDS and to memory -> the touched groups fold their 64 records from LDS.
+//   Two dependent memory round trips per round (bucket records, points) and six barriers.
+// The group test is exact for the same reason the bucket test is: a group's box contains its
+// buckets' boxes and its maximum bounds theirs, and every term is rounded monotonically, so a group
+// that fails the test holds no bucket that would pass. Same distances, same comparison, same
+// indices as the launched rounds (tests/test_gpu_topology.py).
+static constexpr int kTailThreads = 1024;
+static constexpr int kTailWaves = kTailThreads / 64;
+static constexpr int kTailGroup = 64;       // buckets per group: a lane each
+static constexpr int kTailMaxGroups = 1024;  // LDS: 88 bytes per group
+
+struct TailRec {  // a bucket's (or a group's) farthest point, with its coordinates
+  double d;
+  int idx, pos;
+  double x, y, z;
+};
+
+// ---- the best of a wave without LDS traffic -----------------------------------------------------
+// A butterfly of __shfl_xor over a 40-byte record is 60 ds_bpermute instructions (2 600 cycles with
+// sixteen waves at it: measured, it was the largest part of a round). Instead: the maximum of the
+// order-preserving 64-bit image of d by DPP row operations (four steps inside each row of 16 lanes,
+// then four scalar reads, one per row), the lowest index among the lanes that hold it the same way,
+// and the winner's other fields by v_readlane. No LDS, ~100 cycles.
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp32(unsigned v) {
+  return unsigned(__builtin_amdgcn_update_dpp(0, int(v), CTRL, 0xF, 0xF, false));
+}
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_max64(unsigned long long k) {
+  const unsigned long long o = (static_cast<unsigned long long>(dpp32<CTRL>(unsigned(k >> 32))) << 32) |
+                               dpp32<CTRL>(unsigned(k));
+  return o > k ? o : k;
+}
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k) {  // all 64 lanes active
+  k = dpp_max64<0xB1>(k);   // quad_perm [1,0,3,2]
+  k = dpp_max64<0x4E>(k);   // quad_perm [2,3,0,1]
+  k = dpp_max64<0x124>(k);  // row_ror:4
+  k = dpp_max64<0x128>(k);  // row_ror:8 -> every lane holds its row's maximum
+  auto rl = [&](int lane) {
+    return (static_cast<unsigned long long>(unsigned(__builtin_amdgcn_readlane(int(k >> 32), lane))) << 32) |
+           unsigned(__builtin_amdgcn_readlane(int(unsigned(k)), lane));
+  };
+  const unsigned long long a = rl(0), b = rl(16), c = rl(32), d = rl(48);
+  const unsigned long long ab = a > b ? a : b, cd = c > d ? c : d;
+  return ab > cd ? ab : cd;
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned k) {
+  auto step = [](unsigned v, unsigned o) { return o > v ? o : v; };
+  k = step(k, dpp32<0xB1>(k));
+  k = step(k, dpp32<0x4E>(k));
+  k = step(k, dpp32<0x124>(k));
+  k = step(k, dpp32<0x128>(k));
+  const unsigned a = unsigned(__builtin_amdgcn_readlane(int(k), 0)), b = unsigned(__builtin_amdgcn_readlane(int(k), 16)),
+                 c = unsigned(__builtin_amdgcn_readlane(int(k), 32)), d = unsigned(__builtin_amdgcn_readlane(int(k), 48));
+  return step(step(a, b), step(c, d));
+}
+__device__ __forceinline__ unsigned long long ord_bits(double x) {  // order-preserving double -> uint64
+  const unsigned long long b = static_cast<unsigned long long>(__double_as_longlong(x));
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double lane_double(double v, int src) {
+  const long long b = __double_as_longlong(v);
+  const unsigned lo = unsigned(__builtin_amdgcn_readlane(int(unsigned(b)), src));
+  const unsigned hi = unsigned(__builtin_amdgcn_readlane(int(unsigned(b >> 32)), src));
+  return __longlong_as_double((static_cast<long long>(hi) << 32) | lo);
+}
+// the best record of the wave (farthest, lowest index on ties), in every lane; all lanes active
+__device__ __forceinline__ TailRec tail_best(TailRec m) {
+  const unsigned long long kd = ord_bits(m.d);
+  const unsigned long long top = wave_max_u64(kd);
+  const unsigned ki = kd == top ? 0x7FFFFFFFu - unsigned(m.idx) : 0u;  // indices are below 2^31
+  const unsigned ti = wave_max_u32(ki);
+  const unsigned long long who = __ballot(kd == top && ki == ti);
+  const int src = __builtin_amdgcn_readfirstlane(__ffsll(who) - 1);
+  TailRec r;
+  r.d = lane_double(m.d, src);
+  r.idx = __builtin_amdgcn_readlane(m.idx, src);
+  r.pos = __builtin_amdgcn_readlane(m.pos, src);
+  r.x = lane_double(m.x, src);
+  r.y = lane_double(m.y, src);
+  r.z = lane_double(m.z, src);
+  return r;
+}
+
+__device__ __forceinline__ unsigned spread3(unsigned v) {  // 10 bits -> every third bit
+  v &= 0x3FFu;
+  v = (v | (v << 16)) & 0x030000FFu;
+  v = (v | (v << 8)) & 0x0300F00Fu;
+  v = (v | (v << 4)) & 0x030C30C3u;
+  v = (v | (v << 2)) & 0x09249249u;
+  return v;
+}
+
+// Morton key of every bucket's cell (buckets are listed cell by cell, x fastest)
+__global__ __launch_bounds__(256) void k_fps_tail_key(int nb, int nx, int ny, const int32_t* __restrict__ bstart,
+                                                      const int32_t* __restrict__ cell_of,
+                                                      uint32_t* __restrict__ key, int32_t* __restrict__ ident) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= nb) return;
+  const int c = cell_of[bstart[b]];
+  const unsigned cx = unsigned(c % nx), cy = unsigned((c / nx) % ny), cz = unsigned(c / (nx * ny));
+  key[b] = spread3(cx) | (spread3(cy) << 1) | (spread3(cz) << 2);
+  ident[b] = b;
+}
+
+// the buckets in their new order: record with coordinates, box, point range
+__global__ __launch_bounds__(256) void k_fps_tail_prep(int nb, const int32_t* __restrict__ perm,
+                                                       const int32_t* __restrict__ bstart,
+                                                       const double* __restrict__ aabb, const Far* __restrict__ val,
+                                                       const double* __restrict__ sx, const double* __restrict__ sy,
+                                                       const double* __restrict__ sz, TailRec* __restrict__ trec,
+                                                       double* __restrict__ tbox, int2* __restrict__ tq) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= nb) return;
+  const int b = perm[j];
+  const Far v = val[b];
+  trec[j] = TailRec{v.d, v.idx, v.pos, sx[v.pos], sy[v.pos], sz[v.pos]};
+#pragma unroll
+  for (int a = 0; a < 6; ++a) tbox[6 * size_t(j) + a] = aabb[6 * size_t(b) + a];
+  tq[j] = make_int2(bstart[b], bstart[b + 1]);
+}
+
+__global__ __launch_bounds__(kTailThreads) void k_fps_tail(
+    int s_begin, int s_end, int nb, int ng, const int2* __restrict__ tq, const double* __restrict__ tbox,
+    const int32_t* __restrict__ order, const double* __restrict__ sx, const double* __restrict__ sy,
+    const double* __restrict__ sz, double* __restrict__ dist, TailRec* __restrict__ trec /*in place*/,
+    int32_t* __restrict__ out, unsigned long long* __restrict__ dbg /*diagnostic build: phase clocks, may be null*/) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, fine[5] = {0, 0, 0, 0, 0};
+  TailRec* gmax = reinterpret_cast<TailRec*>(smem);                                // [ng]
+  double* gbox = reinterpret_cast<double*>(smem + size_t(ng) * sizeof(TailRec));   // [ng][6]
+  __shared__ TailRec grec[kTailWaves][kTailGroup];  // the records of the groups of the current batch
+  __shared__ TailRec red[kTailWaves];
+  __shared__ int glist[kTailMaxGroups];
+  __shared__ int4 blist[kTailWaves * kTailGroup];  // (q0, q1, slot in grec, bucket)
+  __shared__ int n_g, n_b;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const TailRec none{-1.0, 0x7FFFFFFF, 0, 0.0, 0.0, 0.0};
+  // group records from the bucket records
+  for (int g = wave; g < ng; g += kTailWaves) {
+    const int b = g * kTailGroup + lane;
+    TailRec m = none;
+    double lo[3] = {__builtin_inf(), __builtin_inf(), __builtin_inf()};
+    double hi[3] = {-__builtin_inf(), -__builtin_inf(), -__builtin_inf()};
+    if (b < nb) {
+      m = trec[b];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        lo[a] = tbox[6 * size_t(b) + a];
+        hi[a] = tbox[6 * size_t(b) + 3 + a];
+      }
+    }
+    m = tail_best(m);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        lo[a] = fmin(lo[a], __shfl_xor(lo[a], off, 64));
+        hi[a] = fmax(hi[a], __shfl_xor(hi[a], off, 64));
+      }
+    if (lane == 0) {
+      gmax[g] = m;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        gbox[6 * g + a] = lo[a];
+        gbox[6 * g + 3 + a] = hi[a];
+      }
+    }
+  }
+  __syncthreads();
+  auto axis = [](double p, double lo, double hi) { return p < lo ? lo - p : (p > hi ? p - hi : 0.0); };
+  const unsigned long long clk0 = dbg ? clock64() : 0;
+  for (int s = s_begin; s < s_end; ++s) {
+    unsigned long long t0 = dbg ? wall_clock64() : 0;
+    // 1. the farthest point of all = the best group maximum
+    unsigned long long c0 = dbg ? clock64() : 0;
+    TailRec b = none;
+    for (int g = tid; g < ng; g += kTailThreads) {
+      const TailRec c = gmax[g];
+      if (better(c.d, c.idx, b.d, b.idx)) b = c;
+    }
+    if (dbg) { const unsigned long long t = clock64(); fine[0] += t - c0; c0 = t; }
+    b = tail_best(b);
+    if (dbg) { const unsigned long long t = clock64(); fine[1] += t - c0; c0 = t; }
+    if (lane == 0) red[wave] = b;
+    if (tid == 0) n_g = 0;
+    __syncthreads();
+    if (dbg) { const unsigned long long t = clock64(); fine[2] += t - c0; c0 = t; }
+    // every wave folds the sixteen wave results itself: no second barrier, no serial loop
+    const TailRec top = tail_best(red[lane & (kTailWaves - 1)]);
+    if (tid == 0) out[s] = top.idx;
+    if (dbg) { const unsigned long long t = clock64(); fine[3] += t - c0; c0 = t; }
+    const double px = top.x, py = top.y, pz = top.z;
+    if (dbg) { const unsigned long long t = wall_clock64(); acc[0] += t - t0; t0 = t; }
+    // 2. groups the sample can still improve
+    for (int g = tid; g < ng; g += kTailThreads) {
+      const double t0 = axis(px, gbox[6 * g], gbox[6 * g + 3]), t1 = axis(py, gbox[6 * g + 1], gbox[6 * g + 4]),
+                   t2 = axis(pz, gbox[6 * g + 2], gbox[6 * g + 5]);
+      double m2 = t0 * t0;
+      m2 = m2 + t1 * t1;
+      m2 = m2 + t2 * t2;
+      if (m2 < gmax[g].d) glist[atomicAdd(&n_g, 1)] = g;
+    }
+    __syncthreads();
+    const int ngl = n_g;
+    if (dbg) { const unsigned long long t = wall_clock64(); acc[1] += t - t0; t0 = t; acc[5] += ngl; }
+    for (int g0 = 0; g0 < ngl; g0 += kTailWaves) {  // batches of one group per wave
+      if (tid == 0) n_b = 0;
+      __syncthreads();
+      // 3. the batch's buckets: record and box, one gather; the records stay in LDS
+      const int q = g0 + wave;
+      if (q < ngl) {
+        const int bk = glist[q] * kTailGroup + lane;
+        TailRec r = none;
+        bool hit = false;
+        int2 range = make_int2(0, 0);
+        if (bk < nb) {
+          r = trec[bk];
+          range = tq[bk];
+          const double t0 = axis(px, tbox[6 * size_t(bk)], tbox[6 * size_t(bk) + 3]),
+                       t1 = axis(py, tbox[6 * size_t(bk) + 1], tbox[6 * size_t(bk) + 4]),
+                       t2 = axis(pz, tbox[6 * size_t(bk) + 2], tbox[6 * size_t(bk) + 5]);
+          double m2 = t0 * t0;
+          m2 = m2 + t1 * t1;
+          m2 = m2 + t2 * t2;
+          hit = m2 < r.d;
+        }
+        grec[wave][lane] = r;
+        const unsigned long long mask = __ballot(hit);
+        if (mask) {
+          int base = 0;
+          if (lane == 0) base = atomicAdd(&n_b, __popcll(mask));
+          base = __shfl(base, 0, 64);
+          if (hit) blist[base + __popcll(mask & ((1ull << lane) - 1ull))] = make_int4(range.x, range.y, wave * kTailGroup + lane, bk);
+        }
+      }
+      __syncthreads();
+      // 4. update the listed buckets, a wave each (at most four points per lane)
+      const int nbl = n_b;
+      if (dbg) { const unsigned long long t = wall_clock64(); acc[2] += t - t0; t0 = t; acc[6] += nbl; }
+      for (int w = wave; w < nbl; w += kTailWaves) {
+        const int4 job = blist[w];
+        const int wq0 = job.x, wq1 = job.y;
+        double vx[4], vy[4], vz[4], old[4];
+        int id[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = wq0 + lane + 64 * u;
+          const int ii = i < wq1 ? i : wq0;
+          vx[u] = sx[ii];
+          vy[u] = sy[ii];
+          vz[u] = sz[ii];
+          old[u] = dist[ii];
+          id[u] = order[ii];
+        }
+        TailRec m = none;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = wq0 + lane + 64 * u;
+          if (i < wq1) {
+            const double t0 = vx[u] - px, t1 = vy[u] - py, t2 = vz[u] - pz;
+            double d = t0 * t0;
+            d = d + t1 * t1;
+            d = d + t2 * t2;
+            d = d < old[u] ? d : old[u];
+            dist[i] = d;
+            if (better(d, id[u], m.d, m.idx)) m = TailRec{d, id[u], i, vx[u], vy[u], vz[u]};
+          }
+        }
+        m = tail_best(m);
+        if (lane == 0) {
+          (&grec[0][0])[job.z] = m;
+          trec[job.w] = m;
+        }
+      }
+      __syncthreads();
+      if (dbg) { const unsigned long long t = wall_clock64(); acc[3] += t - t0; t0 = t; }
+      // 5. the batch's groups fold their records again
+      if (q < ngl) {
+        const TailRec m = tail_best(grec[wave][lane]);
+        if (lane == 0) gmax[glist[q]] = m;
+      }
+      __syncthreads();
+      if (dbg) { const unsigned long long t = wall_clock64(); acc[4] += t - t0; t0 = t; }
+    }
+  }
+  if (dbg && tid == 0) {
+    acc[7] = clock64() - clk0;  // shader cycles of the whole loop (against the 100 MHz ticks: the clock it ran at)
+    for (int k = 0; k < 8; ++k) dbg[k] = acc[k];
+    for (int k = 0; k < 5; ++k) dbg[8 + k] = fine[k];
+  }
+}
+
 static bool fps_prune_enabled() {  // PYQSM_FPS_PRUNE=0: the whole-cloud rounds at every size
   const char* e = getenv("PYQSM_FPS_PRUNE");
   return !(e && e[0] == '0');
@@ -418,6 +723,66 @@ static int fps_pruned(Ctx* c, const double* d_xyz, int N, int S, int start_index
       PQ_HIP(hipMemcpyAsync(&D, dlog + (s - 1), 8, hipMemcpyDeviceToHost, c->stream));
       PQ_HIP(hipStreamSynchronize(c->stream));
       if (std::sqrt(D) < 3.0 * g.cell) late = true;
+      // from here on a round touches a few dozen buckets. PYQSM_FPS_TAIL=1: all the remaining rounds in
+      // one launch of one workgroup (k_fps_tail). OFF by default — measured (1 M points, 100 k samples,
+      // round 3): 6.5 us a round against 5.96 us for a launch per round. One CU moves ~50 GB/s, and a round
+      // reads ~50 KB of bucket records (8.5 groups of 64 in reach) and ~130 KB of points (12 buckets of
+      // 256): 2.2 + 2.8 us of its 6.5 are that bandwidth, which the launched rounds spread over the
+      // chip. What the resident version needs is buckets that are compact against the samples' reach
+      // (points in Morton order of a ~10 cm grid, 64 to a bucket), not a different kind of launch.
+      const int ng = ceil_div(int(nb), kTailGroup);
+      const char* te = getenv("PYQSM_FPS_TAIL");
+      if (late && ng <= kTailMaxGroups && te && te[0] == '1') {
+        const size_t lds = size_t(ng) * (sizeof(TailRec) + 48);
+        static std::atomic<uint64_t> attr_set{0};
+        const uint64_t bit = 1ull << (c->device & 63);
+        if (!(attr_set.load(std::memory_order_acquire) & bit)) {
+          PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fps_tail),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+          attr_set.fetch_or(bit, std::memory_order_release);
+        }
+        const Far* cur = (s & 1) ? vb : va;  // the bucket records after sample s - 1
+        unsigned long long* d_dbg = nullptr;
+        if (getenv("PYQSM_FPS_TRACE")) PQ_TRY(c->arena.get(16, &d_dbg));
+        // buckets in Morton order of their cells: 64 consecutive ones are a compact blob
+        uint32_t* key;
+        int32_t* perm;
+        TailRec* trec;
+        double* tbox;
+        int2* tq;
+        PQ_TRY(c->arena.get(size_t(nb), &key));
+        PQ_TRY(c->arena.get(size_t(nb), &perm));
+        PQ_TRY(c->arena.get(size_t(nb), &trec));
+        PQ_TRY(c->arena.get(size_t(nb) * 6, &tbox));
+        PQ_TRY(c->arena.get(size_t(nb), &tq));
+        hipLaunchKernelGGL(k_fps_tail_key, dim3(ceil_div(nb, 256)), dim3(256), 0, c->stream, int(nb), g.nx, g.ny,
+                           static_cast<const int32_t*>(bstart), static_cast<const int32_t*>(g.cell_of), key, perm);
+        PQ_HIP(hipGetLastError());
+        PQ_TRY(stable_sort_pairs_u32(c, &key, &perm, nb, 30));
+        hipLaunchKernelGGL(k_fps_tail_prep, dim3(ceil_div(nb, 256)), dim3(256), 0, c->stream, int(nb),
+                           static_cast<const int32_t*>(perm), static_cast<const int32_t*>(bstart),
+                           static_cast<const double*>(aabb), cur, static_cast<const double*>(g.sx),
+                           static_cast<const double*>(g.sy), static_cast<const double*>(g.sz), trec, tbox, tq);
+        hipLaunchKernelGGL(k_fps_tail, dim3(1), dim3(kTailThreads), lds, c->stream, s, S, int(nb), ng,
+                           static_cast<const int2*>(tq), static_cast<const double*>(tbox),
+                           static_cast<const int32_t*>(g.order), static_cast<const double*>(g.sx),
+                           static_cast<const double*>(g.sy), static_cast<const double*>(g.sz), dist, trec, d_out,
+                           d_dbg);
+        if (d_dbg) {
+          unsigned long long h[16];
+          PQ_HIP(hipMemcpyAsync(h, d_dbg, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+          PQ_HIP(hipStreamSynchronize(c->stream));
+          const double r = double(S - s);
+          fprintf(stderr, "fps tail per round (100 MHz ticks): argmax %.1f, group test %.1f, bucket gather %.1f, update %.1f, "
+                  "fold %.1f; groups in reach %.2f, buckets updated %.2f; shader clock %.0f MHz\n", h[0] / r, h[1] / r,
+                  h[2] / r, h[3] / r, h[4] / r, h[5] / r, h[6] / r,
+                  100.0 * double(h[7]) / double(h[0] + h[1] + h[2] + h[3] + h[4]));
+          fprintf(stderr, "  argmax in shader cycles: scan %.0f, wave fold %.0f, barrier %.0f, thread 0 %.0f, barrier %.0f\n",
+                  h[8] / r, h[9] / r, h[10] / r, h[11] / r, h[12] / r);
+        }
+        if (getenv("PYQSM_FPS_TRACE")) fprintf(stderr, "fps: rounds %d .. %d in one launch (%d groups)\n", s, S, ng);
+        break;
+      }
     }
     // early: every bucket is in reach, one per wave; late: a block looks at 64 buckets' boxes
     // (late: 256 / 128 / 64 / 32 / 16 buckets per block -> 0.654 / 0.611 / 0.596 / 0.624 / 0.708 s for 100 k samples)
