@@ -737,12 +737,18 @@ static int dbscan_device(Ctx* c, const double* xyz, int64_t n, double eps, int32
   int* run_min;
   PQ_TRY(c->arena.get(size_t(n), &run_min));
   PQ_TRY(c->arena.get(size_t(n), &list));
-  PQ_TRY(c->arena.get(2, &list_cnt));
+  // [0] listed sub-cells, [1] stragglers of the core pass, [2] scratch of the union phase, [3] non-core
+  // points of the label pass. The binning leaves four zeroed ints behind for this (no memset launches).
+  if (sub.zeroed4) {
+    list_cnt = sub.zeroed4;
+  } else {
+    PQ_TRY(c->arena.get(4, &list_cnt));
+    PQ_HIP(hipMemsetAsync(list_cnt, 0, 16, c->stream));
+  }
   int32_t* rest;
   PQ_TRY(c->arena.get(size_t(n), &rest));
   {
     ProfScope ps(c, "dbscan_core");
-    PQ_HIP(hipMemsetAsync(list_cnt + 1, 0, 4, c->stream));
     unsigned long long* d_tests = nullptr;
     if (c->prof >= 2) {
       PQ_TRY(c->arena.get(256, &d_tests));
@@ -827,12 +833,11 @@ static int dbscan_device(Ctx* c, const double* xyz, int64_t n, double eps, int32
   }
   {
     ProfScope ps(c, "dbscan_label");
-    PQ_HIP(hipMemsetAsync(list_cnt + 1, 0, 4, c->stream));
     hipLaunchKernelGGL(k_labels, grid, block, 0, c->stream, N, core, parent, min_orig, flag, g.order,
-                       labels, is_core, rest, list_cnt + 1);
+                       labels, is_core, rest, list_cnt + 3);
     on_coords(g, [&](auto co) {
       hipLaunchKernelGGL(k_labels_border<decltype(co)>, dim3(std::min<int64_t>(8192, ceil_div(n, 64))), block, 0,
-                         c->stream, rest, list_cnt + 1, st, g.start, g.cell_of, co, r2, core, parent, min_orig,
+                         c->stream, rest, list_cnt + 3, st, g.start, g.cell_of, co, r2, core, parent, min_orig,
                          flag, g.order, labels);
     });
     PQ_HIP(hipGetLastError());

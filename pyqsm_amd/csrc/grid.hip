@@ -1,6 +1,7 @@
 // grid.hip — bounding box, cell counting sort (see grid.hpp).
 #include "grid.hpp"
 
+#include <atomic>
 #include <cmath>
 
 namespace pyqsm {
@@ -789,8 +790,8 @@ __global__ __launch_bounds__(256) void k_order_big(const int32_t* __restrict__ b
 //   A1  k_bk_hist     cell and octant of every point; per block an LDS histogram over the BUCKETS
 //                     (a bucket = 4096 or 8192 consecutive cell ids), flushed with one atomic per
 //                     non-empty (block, bucket), lanes on consecutive buckets
-//       k_bk_scan     exclusive scan of the <= 16384 bucket totals (one block)
-//   A2  k_bk_scatter  the same LDS histogram again, this time returning the rank inside the block;
+//   A2  k_bk_scatter  every block scans the <= 16384 bucket totals itself (no one-block kernel between the
+//                     passes); the same LDS histogram again, this time returning the rank inside the block;
 //                     a block reserves its share of every bucket with one returning atomic
 //                     (same shape) and writes the 32-byte records bucket by bucket
 //   B   k_bk_sort     one block per bucket, everything in LDS: a count per cell (arrival rank) and
@@ -842,10 +843,11 @@ __global__ __launch_bounds__(256) void k_bk_hist(const double* __restrict__ xyz,
   }
 }
 
-// one block: bstart[b] = points in buckets before b (bstart[nbk] = n), cursor = a copy to reserve from
+// one block: bstart[b] = points in buckets before b (bstart[nbk] = n). Used for directories of many
+// buckets; up to kBkFusedScan buckets every block of k_bk_scatter scans the totals itself instead.
+static constexpr int kBkFusedScan = 4096;
 __global__ __launch_bounds__(1024) void k_bk_scan(int nbk, const int32_t* __restrict__ tot,
-                                                  int32_t* __restrict__ bstart,
-                                                  int32_t* __restrict__ cursor) {
+                                                  int32_t* __restrict__ bstart) {
   __shared__ int32_t wsum[16];
   const int per = (nbk + 1023) / 1024;  // <= 16
   const int b0 = threadIdx.x * per;
@@ -866,10 +868,7 @@ __global__ __launch_bounds__(1024) void k_bk_scan(int nbk, const int32_t* __rest
   int32_t run = incl - s;
   for (int q = 0; q < w; ++q) run += wsum[q];
   for (int k = 0; k < per; ++k) {
-    if (b0 + k < nbk) {
-      bstart[b0 + k] = run;
-      cursor[b0 + k] = run;
-    }
+    if (b0 + k < nbk) bstart[b0 + k] = run;
     run += v[k];
   }
   if (threadIdx.x == 1023) bstart[nbk] = run;
@@ -877,10 +876,41 @@ __global__ __launch_bounds__(1024) void k_bk_scan(int nbk, const int32_t* __rest
 
 __global__ __launch_bounds__(256) void k_bk_scatter(const double* __restrict__ xyz, int64_t n, int nbk,
                                                     int bits, const int32_t* __restrict__ key_tmp,
-                                                    int32_t* __restrict__ cursor,
-                                                    PointRec* __restrict__ bucketed) {
-  extern __shared__ __attribute__((aligned(16))) int32_t h[];
+                                                    const int32_t* __restrict__ tot,
+                                                    int32_t* __restrict__ cursor /*zeroed*/,
+                                                    int32_t* __restrict__ bstart /*[nbk + 1]: written by block 0
+                                                    (fused) or read (scanned by k_bk_scan)*/,
+                                                    int fused, PointRec* __restrict__ bucketed) {
+  extern __shared__ __attribute__((aligned(16))) int32_t h[];  // [nbk] ranks / shares (+ [nbk] bucket starts: fused)
+  int32_t* pre = h + nbk;
+  __shared__ int32_t wsum[4];
   for (int b = threadIdx.x; b < nbk; b += 256) h[b] = 0;
+  // fused: every block scans the bucket totals itself (<= 16 KB out of L2: cheaper than a one-block
+  // kernel of its own between the two passes): thread t owns `per` consecutive buckets
+  if (fused) {
+    const int per = (nbk + 255) / 256, b0 = threadIdx.x * per;
+    int32_t s = 0;
+    for (int k = 0; k < per; ++k) s += b0 + k < nbk ? tot[b0 + k] : 0;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int32_t incl = s;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int32_t t = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += t;
+    }
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    int32_t run = incl - s;
+    for (int q = 0; q < w; ++q) run += wsum[q];
+    for (int k = 0; k < per; ++k) {
+      if (b0 + k < nbk) {
+        pre[b0 + k] = run;
+        if (blockIdx.x == 0) bstart[b0 + k] = run;
+        run += tot[b0 + k];
+      }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 255) bstart[nbk] = run;
+  }
   __syncthreads();
   const int64_t base = int64_t(blockIdx.x) * kBkPts;
   int key[kBkPts / 256], lr[kBkPts / 256];
@@ -893,7 +923,7 @@ __global__ __launch_bounds__(256) void k_bk_scatter(const double* __restrict__ x
   __syncthreads();
   for (int b = threadIdx.x; b < nbk; b += 256) {
     const int v = h[b];
-    if (v) h[b] = atomicAdd(&cursor[b], v);  // this block's share of the bucket starts here
+    if (v) h[b] = (fused ? pre[b] : bstart[b]) + atomicAdd(&cursor[b], v);  // this block's share of the bucket
   }
   __syncthreads();
 #pragma unroll
@@ -1220,22 +1250,24 @@ static int build_grid_bucketed(Ctx* c, const double* xyz, int64_t n, DevGrid* g)
   const int64_t nbk = (g->ncell + (int64_t(1) << bits)) >> bits;
   int32_t *tot, *bstart, *cursor, *key_tmp, *rank_tmp;
   PointRec* bucketed;
-  PQ_TRY(c->arena.get(size_t(nbk), &tot));
+  PQ_TRY(c->arena.get(size_t(nbk) * 2, &tot));  // totals, then the reservation cursors: one memset
+  cursor = tot + nbk;
   PQ_TRY(c->arena.get(size_t(nbk) + 1, &bstart));
-  PQ_TRY(c->arena.get(size_t(nbk), &cursor));
   PQ_TRY(c->arena.get(size_t(n), &key_tmp));
   PQ_TRY(c->arena.get(size_t(n), &rank_tmp));
   PQ_TRY(c->arena.get(size_t(n), &bucketed));
   g->occ_blocks = int(nbk);
   PQ_TRY(c->arena.get(size_t(nbk), &g->occ_part));
-  PQ_HIP(hipMemsetAsync(tot, 0, size_t(nbk) * 4, c->stream));
+  PQ_HIP(hipMemsetAsync(tot, 0, size_t(nbk) * 8, c->stream));
   GridParams gp{g->minx, g->miny, g->minz, g->inv_cell, g->nx, g->ny, g->nz};
   const dim3 ga(ceil_div(n, kBkPts)), blk(256);
   const size_t lds = size_t(nbk) * 4;
+  const int fused = nbk <= kBkFusedScan;
   hipLaunchKernelGGL(k_bk_hist<2>, ga, blk, lds, c->stream, xyz, n, gp, 0, 0, 0, AxisMap{nullptr, nullptr, nullptr},
                      int(nbk), bits, key_tmp, tot);
-  hipLaunchKernelGGL(k_bk_scan, dim3(1), dim3(1024), 0, c->stream, int(nbk), tot, bstart, cursor);
-  hipLaunchKernelGGL(k_bk_scatter, ga, blk, lds, c->stream, xyz, n, int(nbk), bits, key_tmp, cursor, bucketed);
+  if (!fused) hipLaunchKernelGGL(k_bk_scan, dim3(1), dim3(1024), 0, c->stream, int(nbk), tot, bstart);
+  hipLaunchKernelGGL(k_bk_scatter, ga, blk, fused ? 2 * lds : lds, c->stream, xyz, n, int(nbk), bits, key_tmp, tot,
+                     cursor, bstart, fused, bucketed);
   if (bits == 12)
     hipLaunchKernelGGL(k_bk_sort_plain<12>, dim3(unsigned(nbk)), dim3(512), 0, c->stream, g->ncell + 1, bstart,
                        bucketed, rank_tmp, g->start, g->order, g->cell_of, g->sx, g->sy, g->sz, g->p4, g->occ_part);
@@ -1256,10 +1288,12 @@ int build_grid_octants(Ctx* c, const double* xyz, int64_t n, double min_cell, in
   double mn[3], mx[3];
   // the bucket totals and the big-cell counter of the two-level sort below: cleared by the
   // bounding box's fold kernel on its way (two memset launches less)
+  // layout: [kBkMax totals | kBkMax reservation cursors | big-cell counter | four spare zeros for the caller]
   int32_t* tot_big = nullptr;
-  PQ_TRY(c->arena.get(size_t(kBkMax) + 1, &tot_big));
+  PQ_TRY(c->arena.get(size_t(2 * kBkMax) + 5, &tot_big));
   bool all_f32 = false;
-  PQ_TRY(cloud_bbox(c, xyz, n, mn, mx, &all_f32, tot_big, kBkMax + 1));
+  PQ_TRY(cloud_bbox(c, xyz, n, mn, mx, &all_f32, tot_big, 2 * kBkMax + 5));
+  sub->zeroed4 = tot_big + 2 * kBkMax + 1;
   {
     const char* f32_env = getenv("PYQSM_COORD_F32");  // "0": keep fp64 storage (A/B comparisons)
     if (f32_env && !strcmp(f32_env, "0")) all_f32 = false;
@@ -1354,14 +1388,13 @@ int build_grid_octants(Ctx* c, const double* xyz, int64_t n, double min_cell, in
   PQ_TRY(c->arena.get(size_t(n), &sub->sub_of));
   PQ_TRY(c->arena.get(size_t(n) * 8, &sub->rec));
   PQ_TRY(c->arena.get(size_t(n) / kBigCell + 2, &big_list));
-  big_cnt = tot_big + kBkMax;
+  big_cnt = tot_big + 2 * kBkMax;
   GridParams gp{g->minx, g->miny, g->minz, g->inv_cell, g->nx, g->ny, g->nz};
   if (bucketed_path) {
-    int32_t *tot = tot_big, *bstart, *cursor;
+    int32_t *tot = tot_big, *bstart, *cursor = tot_big + kBkMax;
     uint8_t* oct_rank;
     PointRec* bucketed;
     PQ_TRY(c->arena.get(size_t(nbk) + 1, &bstart));
-    PQ_TRY(c->arena.get(size_t(nbk), &cursor));
     PQ_TRY(c->arena.get(size_t(n), &oct_rank));
     PQ_TRY(c->arena.get(size_t(n), &bucketed));
     const dim3 ga(ceil_div(n, kBkPts));
@@ -1372,9 +1405,10 @@ int build_grid_octants(Ctx* c, const double* xyz, int64_t n, double min_cell, in
     else
       hipLaunchKernelGGL(k_bk_hist<0>, ga, blk, lds, c->stream, xyz, n, gp, raw[0], raw[1], raw[2], am,
                          int(nbk), bits, cell_tmp, tot);
-    hipLaunchKernelGGL(k_bk_scan, dim3(1), dim3(1024), 0, c->stream, int(nbk), tot, bstart, cursor);
-    hipLaunchKernelGGL(k_bk_scatter, ga, blk, lds, c->stream, xyz, n, int(nbk), bits, cell_tmp, cursor,
-                       bucketed);
+    const int fused = nbk <= kBkFusedScan;
+    if (!fused) hipLaunchKernelGGL(k_bk_scan, dim3(1), dim3(1024), 0, c->stream, int(nbk), tot, bstart);
+    hipLaunchKernelGGL(k_bk_scatter, ga, blk, fused ? 2 * lds : lds, c->stream, xyz, n, int(nbk), bits, cell_tmp, tot,
+                       cursor, bstart, fused, bucketed);
     if (bits == 12)
       hipLaunchKernelGGL(k_bk_sort<12>, dim3(unsigned(nbk)), dim3(512), 0, c->stream, g->ncell + 1, bstart,
                          bucketed, rank_tmp, oct_rank, g->start, g->order, g->cell_of, sub->sub_of, g->sx, g->sy,

@@ -201,6 +201,9 @@ struct SubCells {
   int32_t* sub_beg;  // [8 n]
   int32_t* sub_of;   // [n] sub-cell id of each sorted position
   int4* rec;         // [8 n] (sub_beg, sub_cnt, -1, 0) in one 16-byte record; .z is the caller's
+  // build_grid_octants only: four ints the binning's own kernels left zeroed, for the caller's
+  // counters (spares DBSCAN two memset launches per step); nullptr from subsort_octants
+  int32_t* zeroed4 = nullptr;
 };
 
 // Re-sorts g's point arrays in place (order, sx, sy, sz are replaced by new arena arrays;
