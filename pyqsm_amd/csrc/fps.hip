@@ -369,26 +369,40 @@ __global__ __launch_bounds__(256) void k_fps_pruned(int s, int start_idx, int nb
 }
 
 // ---- the late rounds in ONE launch ------------------------------------------------------------
-// Once the samples' reach is down to a cell or two, a round touches a few dozen buckets: what it
+// Once the samples' reach is down to a cell or two, a round touches a handful of points: what it
 // costs as a launch (5.9 us) is the launch and three dependent round trips across the chip, 100 000
-// times. k_fps_tail runs all remaining rounds inside one workgroup — no grid barrier, nothing that
-// could wait for another block — with a second level over the buckets kept in LDS:
-//   the buckets are put into Morton order of their cells first (k_fps_tail_key / _prep), so that 64
-//   consecutive buckets are a compact blob; a GROUP of 64 keeps its bounding box and its (largest
-//   distance, lowest index, coordinates) in LDS. A round = the best of the group maxima (LDS, the
-//   sample's coordinates come with it: no look-up) -> the groups whose box is closer than their
-//   largest distance (LDS) -> their buckets' records and boxes, one gather, kept in LDS -> the few
-//   buckets the sample can improve are updated, a wave each, exactly as k_fps_pruned does it, the
-//   new record going to LDS and to memory -> the touched groups fold their 64 records from LDS.
-//   Two dependent memory round trips per round (bucket records, points) and six barriers.
-// The group test is exact for the same reason the bucket test is: a group's box contains its
-// buckets' boxes and its maximum bounds theirs, and every term is rounded monotonically, so a group
-// that fails the test holds no bucket that would pass. Same distances, same comparison, same
-// indices as the launched rounds (tests/test_gpu_topology.py).
-static constexpr int kTailThreads = 1024;
+// times. k_fps_tail runs all remaining rounds inside ONE workgroup of four waves — no grid barrier,
+// nothing that could wait for another block — on a hierarchy that is compact against the reach:
+//   the points in Morton order of a 1024^3 grid over the cloud's box, 64 consecutive points = a BUCKET
+//   (bounding box + farthest point, in memory as separate arrays: a wave's gather is eleven contiguous
+//   loads), 16 consecutive buckets = a GROUP and 64 groups = a SUPER, both with box and farthest point in
+//   LDS. A round: supers whose groups changed fold their group maxima again -> the best super maximum is
+//   the sample (its coordinates travel with the record: no look-up) -> supers, then groups whose box is
+//   closer than their largest distance (LDS) -> their buckets' records and boxes, ONE gather, kept in
+//   LDS -> the buckets the sample can improve are updated, a wave each and a point per lane, the loads
+//   of four buckets in flight together; a bucket's farthest point changes only if that very point moved
+//   closer, otherwise its record stands and no reduction runs -> the groups that changed fold their
+//   sixteen records from LDS. Two dependent memory round trips per round and five barriers of four waves.
+// Every box test is exact for the same reason the bucket test of k_fps_pruned is: a parent's box contains
+// its children's boxes and its maximum bounds theirs, and every term is rounded monotonically, so a parent
+// that fails the test holds no child that would pass. Same distances, same comparison, same indices as
+// the launched rounds and as the whole-cloud rounds (tests/test_gpu_topology.py).
+// Measured on the way (1 M points, 100 k samples; a launch per round: 5.95 us): sixteen waves with
+// 256-point buckets in cell order and 64-bucket groups, 40-byte records through __shfl_xor butterflies:
+// 10.3 us a round (a butterfly of a 40-byte record is 60 ds_bpermute: 2 600 cycles with sixteen waves at
+// it); DPP row reductions + v_readlane: 6.5 us, of which 5 us one CU's bandwidth (50 KB of bucket records
+// and 130 KB of points per round); Morton-ordered 64-point buckets, four waves: 8.2 us (array-of-struct
+// records: 250 cache-line requests per gather, buckets updated one after the other); records as separate
+// arrays, 16-bucket groups, four buckets' loads in flight: 6.2 us; supers, dirty tracking and the skipped
+// reductions: 5.3 us.
+static constexpr int kTailThreads = 256;     // four waves: barriers and reductions are the fixed cost of a round
 static constexpr int kTailWaves = kTailThreads / 64;
-static constexpr int kTailGroup = 64;       // buckets per group: a lane each
-static constexpr int kTailMaxGroups = 1024;  // LDS: 88 bytes per group
+static constexpr int kTailBucket = 64;       // points per bucket in the tail: a lane each
+static constexpr int kTailGroup = 16;        // buckets per group: a wave takes four groups at a time
+static constexpr int kTailPerWave = 64 / kTailGroup;
+static constexpr int kTailMaxGroups = 1280;  // LDS: 88 bytes per group (1.3 M points; larger clouds keep the launches)
+static constexpr int kTailUnroll = 4;        // buckets a wave updates with their loads issued side by side
+static constexpr int kTailMaxSupers = (kTailMaxGroups + 63) / 64;
 
 struct TailRec {  // a bucket's (or a group's) farthest point, with its coordinates
   double d;
@@ -449,9 +463,12 @@ __device__ __forceinline__ double lane_double(double v, int src) {
 __device__ __forceinline__ TailRec tail_best(TailRec m) {
   const unsigned long long kd = ord_bits(m.d);
   const unsigned long long top = wave_max_u64(kd);
-  const unsigned ki = kd == top ? 0x7FFFFFFFu - unsigned(m.idx) : 0u;  // indices are below 2^31
-  const unsigned ti = wave_max_u32(ki);
-  const unsigned long long who = __ballot(kd == top && ki == ti);
+  unsigned long long who = __ballot(kd == top);
+  if (who & (who - 1)) {  // several lanes at the maximum (wave-uniform): the lowest index among them
+    const unsigned ki = kd == top ? 0x7FFFFFFFu - unsigned(m.idx) : 0u;  // indices are below 2^31
+    const unsigned ti = wave_max_u32(ki);
+    who = __ballot(kd == top && ki == ti);
+  }
   const int src = __builtin_amdgcn_readfirstlane(__ffsll(who) - 1);
   TailRec r;
   r.d = lane_double(m.d, src);
@@ -472,74 +489,172 @@ __device__ __forceinline__ unsigned spread3(unsigned v) {  // 10 bits -> every t
   return v;
 }
 
-// Morton key of every bucket's cell (buckets are listed cell by cell, x fastest)
-__global__ __launch_bounds__(256) void k_fps_tail_key(int nb, int nx, int ny, const int32_t* __restrict__ bstart,
-                                                      const int32_t* __restrict__ cell_of,
-                                                      uint32_t* __restrict__ key, int32_t* __restrict__ ident) {
-  const int b = blockIdx.x * 256 + threadIdx.x;
-  if (b >= nb) return;
-  const int c = cell_of[bstart[b]];
-  const unsigned cx = unsigned(c % nx), cy = unsigned((c / nx) % ny), cz = unsigned(c / (nx * ny));
-  key[b] = spread3(cx) | (spread3(cy) << 1) | (spread3(cz) << 2);
-  ident[b] = b;
+// Morton key of every point (10 bits per axis over the cloud's box): 64 consecutive points of the
+// sorted order are a compact blob, 64 consecutive blobs a compact group
+__global__ __launch_bounds__(256) void k_fps_tail_key(int n, const double* __restrict__ sx, const double* __restrict__ sy,
+                                                      const double* __restrict__ sz, double mnx, double mny, double mnz,
+                                                      double inv, uint32_t* __restrict__ key, int32_t* __restrict__ ident) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  auto q = [&](double v, double mn) { return unsigned(fmin(fmax((v - mn) * inv, 0.0), 1023.0)); };
+  key[i] = spread3(q(sx[i], mnx)) | (spread3(q(sy[i], mny)) << 1) | (spread3(q(sz[i], mnz)) << 2);
+  ident[i] = i;
 }
 
-// the buckets in their new order: record with coordinates, box, point range
-__global__ __launch_bounds__(256) void k_fps_tail_prep(int nb, const int32_t* __restrict__ perm,
-                                                       const int32_t* __restrict__ bstart,
-                                                       const double* __restrict__ aabb, const Far* __restrict__ val,
-                                                       const double* __restrict__ sx, const double* __restrict__ sy,
-                                                       const double* __restrict__ sz, TailRec* __restrict__ trec,
-                                                       double* __restrict__ tbox, int2* __restrict__ tq) {
+// the points in their new order
+__global__ __launch_bounds__(256) void k_fps_tail_points(int n, const int32_t* __restrict__ perm,
+                                                         const double* __restrict__ sx, const double* __restrict__ sy,
+                                                         const double* __restrict__ sz, const double* __restrict__ dist,
+                                                         const int32_t* __restrict__ order, double* __restrict__ tx,
+                                                         double* __restrict__ ty, double* __restrict__ tz,
+                                                         double* __restrict__ td, int32_t* __restrict__ tid) {
   const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= nb) return;
-  const int b = perm[j];
-  const Far v = val[b];
-  trec[j] = TailRec{v.d, v.idx, v.pos, sx[v.pos], sy[v.pos], sz[v.pos]};
+  if (j >= n) return;
+  const int i = perm[j];
+  tx[j] = sx[i];
+  ty[j] = sy[i];
+  tz[j] = sz[i];
+  td[j] = dist[i];
+  tid[j] = order[i];
+}
+
+// bucket records as separate arrays: a wave's 64 records are eleven contiguous 512-byte loads (the
+// 40- and 48-byte structs cost 250 cache-line requests per wave and ~1.1 us per gather)
+struct TailSoA {
+  double *d, *x, *y, *z;
+  int32_t *idx, *pos;
+  double* box[6];
+};
+__device__ __forceinline__ TailRec soa_load(const TailSoA& t, int b) {
+  return TailRec{t.d[b], t.idx[b], t.pos[b], t.x[b], t.y[b], t.z[b]};
+}
+__device__ __forceinline__ void soa_store(const TailSoA& t, int b, const TailRec& m) {
+  t.d[b] = m.d;
+  t.idx[b] = m.idx;
+  t.pos[b] = m.pos;
+  t.x[b] = m.x;
+  t.y[b] = m.y;
+  t.z[b] = m.z;
+}
+
+// a wave per bucket of 64 consecutive points: bounding box and farthest point
+__global__ __launch_bounds__(256) void k_fps_tail_buckets(int n, int nb, const double* __restrict__ tx,
+                                                          const double* __restrict__ ty, const double* __restrict__ tz,
+                                                          const double* __restrict__ td, const int32_t* __restrict__ tid,
+                                                          TailSoA rec) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= nb) return;
+  const int j = b * kTailBucket + lane;
+  const bool live = j < n;
+  const int jj = live ? j : b * kTailBucket;
+  const double x = tx[jj], y = ty[jj], z = tz[jj];
+  TailRec m{live ? td[jj] : -1.0, live ? tid[jj] : 0x7FFFFFFF, jj, x, y, z};
+  double lo[3] = {x, y, z}, hi[3] = {x, y, z};
 #pragma unroll
-  for (int a = 0; a < 6; ++a) tbox[6 * size_t(j) + a] = aabb[6 * size_t(b) + a];
-  tq[j] = make_int2(bstart[b], bstart[b + 1]);
+  for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      lo[a] = fmin(lo[a], __shfl_xor(lo[a], off, 64));
+      hi[a] = fmax(hi[a], __shfl_xor(hi[a], off, 64));
+    }
+  m = tail_best(m);
+  if (lane == 0) {
+    soa_store(rec, b, m);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      rec.box[a][b] = lo[a];
+      rec.box[3 + a][b] = hi[a];
+    }
+  }
+}
+
+// reductions inside the rows of 16 lanes a group occupies (a wave holds four groups side by side)
+__device__ __forceinline__ TailRec row_best(TailRec m) {
+  auto kmax = [](unsigned long long k) {
+    k = dpp_max64<0xB1>(k);
+    k = dpp_max64<0x4E>(k);
+    k = dpp_max64<0x124>(k);
+    return dpp_max64<0x128>(k);
+  };
+  const unsigned long long kd = ord_bits(m.d);
+  const unsigned long long top = kmax(kd);
+  unsigned ki = kd == top ? 0x7FFFFFFFu - unsigned(m.idx) : 0u;
+  {
+    auto step = [](unsigned v, unsigned o) { return o > v ? o : v; };
+    unsigned k = ki;
+    k = step(k, dpp32<0xB1>(k));
+    k = step(k, dpp32<0x4E>(k));
+    k = step(k, dpp32<0x124>(k));
+    k = step(k, dpp32<0x128>(k));
+    ki = (kd == top && ki == k) ? 1u : 0u;  // this lane is its row's winner
+  }
+  // the winner's fields to every lane of its row: one ds_bpermute per dword from the winner's lane
+  const unsigned long long who = __ballot(ki != 0);
+  const int row = (threadIdx.x & 63) >> 4;
+  const int src = __ffsll((who >> (16 * row)) & 0xFFFFull) - 1 + 16 * row;
+  TailRec r;
+  r.d = __shfl(m.d, src, 64);
+  r.idx = __shfl(m.idx, src, 64);
+  r.pos = __shfl(m.pos, src, 64);
+  r.x = __shfl(m.x, src, 64);
+  r.y = __shfl(m.y, src, 64);
+  r.z = __shfl(m.z, src, 64);
+  return r;
 }
 
 __global__ __launch_bounds__(kTailThreads) void k_fps_tail(
-    int s_begin, int s_end, int nb, int ng, const int2* __restrict__ tq, const double* __restrict__ tbox,
-    const int32_t* __restrict__ order, const double* __restrict__ sx, const double* __restrict__ sy,
-    const double* __restrict__ sz, double* __restrict__ dist, TailRec* __restrict__ trec /*in place*/,
-    int32_t* __restrict__ out, unsigned long long* __restrict__ dbg /*diagnostic build: phase clocks, may be null*/) {
+    int s_begin, int s_end, int n, int nb, int ng, TailSoA rec, const int32_t* __restrict__ tid,
+    const double* __restrict__ tx, const double* __restrict__ ty, const double* __restrict__ tz,
+    double* __restrict__ td, int32_t* __restrict__ out,
+    unsigned long long* __restrict__ dbg /*diagnostic: phase clocks (100 MHz ticks) and counts, may be null*/) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, fine[5] = {0, 0, 0, 0, 0};
+  unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   TailRec* gmax = reinterpret_cast<TailRec*>(smem);                                // [ng]
   double* gbox = reinterpret_cast<double*>(smem + size_t(ng) * sizeof(TailRec));   // [ng][6]
-  __shared__ TailRec grec[kTailWaves][kTailGroup];  // the records of the groups of the current batch
-  __shared__ TailRec red[kTailWaves];
+  __shared__ TailRec grec[kTailWaves][64];  // the records of the groups of the current batch (four per wave)
+  __shared__ TailRec smax[kTailMaxSupers];  // a SUPER = 64 consecutive groups: its farthest point ...
+  __shared__ double sbox[kTailMaxSupers][6];  // ... and box (boxes never change)
+  __shared__ int sdirty[kTailMaxSupers];      // a group of the super changed: its maximum is folded again
+  __shared__ int gdirty[kTailWaves * kTailPerWave];
   __shared__ int glist[kTailMaxGroups];
-  __shared__ int4 blist[kTailWaves * kTailGroup];  // (q0, q1, slot in grec, bucket)
+  __shared__ int2 blist[kTailWaves * 64];  // (bucket, slot in grec)
   __shared__ int n_g, n_b;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid_ = threadIdx.x, lane = tid_ & 63, wave = tid_ >> 6;
+  const int sub = lane / kTailGroup, gl = lane % kTailGroup;  // group slot of the wave, bucket in the group
+  const int ns = (ng + 63) / 64;
   const TailRec none{-1.0, 0x7FFFFFFF, 0, 0.0, 0.0, 0.0};
+  auto axis = [](double p, double lo, double hi) { return p < lo ? lo - p : (p > hi ? p - hi : 0.0); };
+  auto box_d2 = [&](double px, double py, double pz, const double* bx) {
+    const double t0 = axis(px, bx[0], bx[3]), t1 = axis(py, bx[1], bx[4]), t2 = axis(pz, bx[2], bx[5]);
+    double m2 = t0 * t0;
+    m2 = m2 + t1 * t1;
+    return m2 + t2 * t2;
+  };
   // group records from the bucket records
-  for (int g = wave; g < ng; g += kTailWaves) {
-    const int b = g * kTailGroup + lane;
+  for (int g0 = wave * kTailPerWave; g0 < ng; g0 += kTailWaves * kTailPerWave) {
+    const int g = g0 + sub;
+    const int b = g * kTailGroup + gl;
     TailRec m = none;
     double lo[3] = {__builtin_inf(), __builtin_inf(), __builtin_inf()};
     double hi[3] = {-__builtin_inf(), -__builtin_inf(), -__builtin_inf()};
-    if (b < nb) {
-      m = trec[b];
+    if (g < ng && b < nb) {
+      m = soa_load(rec, b);
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
-        lo[a] = tbox[6 * size_t(b) + a];
-        hi[a] = tbox[6 * size_t(b) + 3 + a];
+        lo[a] = rec.box[a][b];
+        hi[a] = rec.box[3 + a][b];
       }
     }
-    m = tail_best(m);
+    m = row_best(m);
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
+    for (int off = 8; off > 0; off >>= 1)
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
         lo[a] = fmin(lo[a], __shfl_xor(lo[a], off, 64));
         hi[a] = fmax(hi[a], __shfl_xor(hi[a], off, 64));
       }
-    if (lane == 0) {
+    if (gl == 0 && g < ng) {
       gmax[g] = m;
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
@@ -549,62 +664,85 @@ __global__ __launch_bounds__(kTailThreads) void k_fps_tail(
     }
   }
   __syncthreads();
-  auto axis = [](double p, double lo, double hi) { return p < lo ? lo - p : (p > hi ? p - hi : 0.0); };
+  // super boxes; every super starts dirty
+  for (int sp = wave; sp < ns; sp += kTailWaves) {
+    const int g = sp * 64 + lane;
+    double lo[3] = {__builtin_inf(), __builtin_inf(), __builtin_inf()};
+    double hi[3] = {-__builtin_inf(), -__builtin_inf(), -__builtin_inf()};
+    if (g < ng) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        lo[a] = gbox[6 * g + a];
+        hi[a] = gbox[6 * g + 3 + a];
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        lo[a] = fmin(lo[a], __shfl_xor(lo[a], off, 64));
+        hi[a] = fmax(hi[a], __shfl_xor(hi[a], off, 64));
+      }
+    if (lane == 0) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        sbox[sp][a] = lo[a];
+        sbox[sp][3 + a] = hi[a];
+      }
+      sdirty[sp] = 1;
+    }
+  }
+  __syncthreads();
   const unsigned long long clk0 = dbg ? clock64() : 0;
   for (int s = s_begin; s < s_end; ++s) {
     unsigned long long t0 = dbg ? wall_clock64() : 0;
-    // 1. the farthest point of all = the best group maximum
-    unsigned long long c0 = dbg ? clock64() : 0;
-    TailRec b = none;
-    for (int g = tid; g < ng; g += kTailThreads) {
-      const TailRec c = gmax[g];
-      if (better(c.d, c.idx, b.d, b.idx)) b = c;
+    // 1. the farthest point of all: supers whose groups changed fold their 64 group maxima again, then
+    //    every wave takes the best of the (at most 20) super maxima itself
+    for (int sp = wave; sp < ns; sp += kTailWaves) {
+      if (!sdirty[sp]) continue;  // wave-uniform
+      const int g = sp * 64 + lane;
+      const TailRec m = tail_best(g < ng ? gmax[g] : none);
+      if (lane == 0) {
+        smax[sp] = m;
+        sdirty[sp] = 0;
+      }
     }
-    if (dbg) { const unsigned long long t = clock64(); fine[0] += t - c0; c0 = t; }
-    b = tail_best(b);
-    if (dbg) { const unsigned long long t = clock64(); fine[1] += t - c0; c0 = t; }
-    if (lane == 0) red[wave] = b;
-    if (tid == 0) n_g = 0;
+    if (tid_ == 0) n_g = 0;
     __syncthreads();
-    if (dbg) { const unsigned long long t = clock64(); fine[2] += t - c0; c0 = t; }
-    // every wave folds the sixteen wave results itself: no second barrier, no serial loop
-    const TailRec top = tail_best(red[lane & (kTailWaves - 1)]);
-    if (tid == 0) out[s] = top.idx;
-    if (dbg) { const unsigned long long t = clock64(); fine[3] += t - c0; c0 = t; }
+    const TailRec top = tail_best(lane < ns ? smax[lane] : none);
+    if (tid_ == 0) out[s] = top.idx;
     const double px = top.x, py = top.y, pz = top.z;
     if (dbg) { const unsigned long long t = wall_clock64(); acc[0] += t - t0; t0 = t; }
-    // 2. groups the sample can still improve
-    for (int g = tid; g < ng; g += kTailThreads) {
-      const double t0 = axis(px, gbox[6 * g], gbox[6 * g + 3]), t1 = axis(py, gbox[6 * g + 1], gbox[6 * g + 4]),
-                   t2 = axis(pz, gbox[6 * g + 2], gbox[6 * g + 5]);
-      double m2 = t0 * t0;
-      m2 = m2 + t1 * t1;
-      m2 = m2 + t2 * t2;
-      if (m2 < gmax[g].d) glist[atomicAdd(&n_g, 1)] = g;
+    // 2. groups the sample can still improve: the supers first, then the groups of the supers in reach
+    for (int sp = wave; sp < ns; sp += kTailWaves) {
+      if (!(box_d2(px, py, pz, sbox[sp]) < smax[sp].d)) continue;  // wave-uniform
+      const int g = sp * 64 + lane;
+      const bool hit = g < ng && box_d2(px, py, pz, gbox + 6 * g) < gmax[g].d;
+      const unsigned long long mask = __ballot(hit);
+      if (mask) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&n_g, __popcll(mask));
+        base = __shfl(base, 0, 64);
+        if (hit) glist[base + __popcll(mask & ((1ull << lane) - 1ull))] = g;
+      }
     }
     __syncthreads();
     const int ngl = n_g;
     if (dbg) { const unsigned long long t = wall_clock64(); acc[1] += t - t0; t0 = t; acc[5] += ngl; }
-    for (int g0 = 0; g0 < ngl; g0 += kTailWaves) {  // batches of one group per wave
-      if (tid == 0) n_b = 0;
+    for (int g0 = 0; g0 < ngl; g0 += kTailWaves * kTailPerWave) {  // batches: four groups per wave
+      if (tid_ == 0) n_b = 0;
+      if (tid_ < kTailWaves * kTailPerWave) gdirty[tid_] = 0;
       __syncthreads();
-      // 3. the batch's buckets: record and box, one gather; the records stay in LDS
-      const int q = g0 + wave;
-      if (q < ngl) {
-        const int bk = glist[q] * kTailGroup + lane;
+      // 3. the batch's buckets: record and box, one gather of contiguous arrays; the records stay in LDS
+      const int q = g0 + wave * kTailPerWave + sub;
+      {
+        const int bk = q < ngl ? glist[q] * kTailGroup + gl : nb;
         TailRec r = none;
         bool hit = false;
-        int2 range = make_int2(0, 0);
         if (bk < nb) {
-          r = trec[bk];
-          range = tq[bk];
-          const double t0 = axis(px, tbox[6 * size_t(bk)], tbox[6 * size_t(bk) + 3]),
-                       t1 = axis(py, tbox[6 * size_t(bk) + 1], tbox[6 * size_t(bk) + 4]),
-                       t2 = axis(pz, tbox[6 * size_t(bk) + 2], tbox[6 * size_t(bk) + 5]);
-          double m2 = t0 * t0;
-          m2 = m2 + t1 * t1;
-          m2 = m2 + t2 * t2;
-          hit = m2 < r.d;
+          r = soa_load(rec, bk);
+          const double bx[6] = {rec.box[0][bk], rec.box[1][bk], rec.box[2][bk], rec.box[3][bk], rec.box[4][bk], rec.box[5][bk]};
+          hit = box_d2(px, py, pz, bx) < r.d;
         }
         grec[wave][lane] = r;
         const unsigned long long mask = __ballot(hit);
@@ -612,63 +750,81 @@ __global__ __launch_bounds__(kTailThreads) void k_fps_tail(
           int base = 0;
           if (lane == 0) base = atomicAdd(&n_b, __popcll(mask));
           base = __shfl(base, 0, 64);
-          if (hit) blist[base + __popcll(mask & ((1ull << lane) - 1ull))] = make_int4(range.x, range.y, wave * kTailGroup + lane, bk);
+          if (hit) blist[base + __popcll(mask & ((1ull << lane) - 1ull))] = make_int2(bk, wave * 64 + lane);
         }
       }
       __syncthreads();
-      // 4. update the listed buckets, a wave each (at most four points per lane)
+      // 4. update the listed buckets, a wave each and a point per lane; the loads of up to kTailUnroll
+      //    buckets are issued before the first is used. A bucket's farthest point changes only if that very
+      //    point moved closer (everybody else can only decrease): otherwise its record stands, no reduction.
       const int nbl = n_b;
       if (dbg) { const unsigned long long t = wall_clock64(); acc[2] += t - t0; t0 = t; acc[6] += nbl; }
-      for (int w = wave; w < nbl; w += kTailWaves) {
-        const int4 job = blist[w];
-        const int wq0 = job.x, wq1 = job.y;
-        double vx[4], vy[4], vz[4], old[4];
-        int id[4];
+      for (int w0 = wave; w0 < nbl; w0 += kTailWaves * kTailUnroll) {
+        double vx[kTailUnroll], vy[kTailUnroll], vz[kTailUnroll], old[kTailUnroll];
+        int id[kTailUnroll], jj[kTailUnroll];
+        int2 job[kTailUnroll];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int i = wq0 + lane + 64 * u;
-          const int ii = i < wq1 ? i : wq0;
-          vx[u] = sx[ii];
-          vy[u] = sy[ii];
-          vz[u] = sz[ii];
-          old[u] = dist[ii];
-          id[u] = order[ii];
+        for (int u = 0; u < kTailUnroll; ++u) {
+          const int w = w0 + u * kTailWaves;
+          job[u] = w < nbl ? blist[w] : make_int2(-1, 0);
+          const int j = job[u].x >= 0 ? job[u].x * kTailBucket + lane : n;
+          jj[u] = j;
+          const int js = j < n ? j : 0;
+          vx[u] = tx[js];
+          vy[u] = ty[js];
+          vz[u] = tz[js];
+          old[u] = td[js];
+          id[u] = tid[js];
         }
-        TailRec m = none;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int i = wq0 + lane + 64 * u;
-          if (i < wq1) {
-            const double t0 = vx[u] - px, t1 = vy[u] - py, t2 = vz[u] - pz;
-            double d = t0 * t0;
-            d = d + t1 * t1;
-            d = d + t2 * t2;
-            d = d < old[u] ? d : old[u];
-            dist[i] = d;
-            if (better(d, id[u], m.d, m.idx)) m = TailRec{d, id[u], i, vx[u], vy[u], vz[u]};
+        for (int u = 0; u < kTailUnroll; ++u) {
+          if (job[u].x < 0) continue;  // wave-uniform
+          const int top_pos = (&grec[0][0])[job[u].y].pos;  // where the bucket's farthest point sits
+          TailRec m = none;
+          bool lowered = false;
+          if (jj[u] < n) {
+            const double u0 = vx[u] - px, u1 = vy[u] - py, u2 = vz[u] - pz;
+            double d = u0 * u0;
+            d = d + u1 * u1;
+            d = d + u2 * u2;
+            if (d < old[u]) {
+              td[jj[u]] = d;
+              lowered = jj[u] == top_pos;
+            } else {
+              d = old[u];
+            }
+            m = TailRec{d, id[u], jj[u], vx[u], vy[u], vz[u]};
           }
-        }
-        m = tail_best(m);
-        if (lane == 0) {
-          (&grec[0][0])[job.z] = m;
-          trec[job.w] = m;
+          if (__ballot(lowered) == 0) continue;  // the record stands
+          m = tail_best(m);
+          if (lane == 0) {
+            (&grec[0][0])[job[u].y] = m;
+            soa_store(rec, job[u].x, m);
+            gdirty[job[u].y / kTailGroup] = 1;
+          }
         }
       }
       __syncthreads();
       if (dbg) { const unsigned long long t = wall_clock64(); acc[3] += t - t0; t0 = t; }
-      // 5. the batch's groups fold their records again
-      if (q < ngl) {
-        const TailRec m = tail_best(grec[wave][lane]);
-        if (lane == 0) gmax[glist[q]] = m;
+      // 5. the batch's groups whose buckets changed fold their records again
+      {
+        const int d0 = gdirty[wave * kTailPerWave], d1 = gdirty[wave * kTailPerWave + 1],
+                  d2 = gdirty[wave * kTailPerWave + 2], d3 = gdirty[wave * kTailPerWave + 3];
+        if (d0 | d1 | d2 | d3) {  // wave-uniform
+          const TailRec m = row_best(grec[wave][lane]);
+          if (gl == 0 && q < ngl && gdirty[wave * kTailPerWave + sub]) {
+            gmax[glist[q]] = m;
+            sdirty[glist[q] >> 6] = 1;
+          }
+        }
       }
       __syncthreads();
       if (dbg) { const unsigned long long t = wall_clock64(); acc[4] += t - t0; t0 = t; }
     }
   }
-  if (dbg && tid == 0) {
-    acc[7] = clock64() - clk0;  // shader cycles of the whole loop (against the 100 MHz ticks: the clock it ran at)
+  if (dbg && tid_ == 0) {
+    acc[7] = clock64() - clk0;
     for (int k = 0; k < 8; ++k) dbg[k] = acc[k];
-    for (int k = 0; k < 5; ++k) dbg[8 + k] = fine[k];
   }
 }
 
@@ -723,53 +879,60 @@ static int fps_pruned(Ctx* c, const double* d_xyz, int N, int S, int start_index
       PQ_HIP(hipMemcpyAsync(&D, dlog + (s - 1), 8, hipMemcpyDeviceToHost, c->stream));
       PQ_HIP(hipStreamSynchronize(c->stream));
       if (std::sqrt(D) < 3.0 * g.cell) late = true;
-      // from here on a round touches a few dozen buckets. PYQSM_FPS_TAIL=1: all the remaining rounds in
-      // one launch of one workgroup (k_fps_tail). OFF by default — measured (1 M points, 100 k samples,
-      // round 3): 6.5 us a round against 5.96 us for a launch per round. One CU moves ~50 GB/s, and a round
-      // reads ~50 KB of bucket records (8.5 groups of 64 in reach) and ~130 KB of points (12 buckets of
-      // 256): 2.2 + 2.8 us of its 6.5 are that bandwidth, which the launched rounds spread over the
-      // chip. What the resident version needs is buckets that are compact against the samples' reach
-      // (points in Morton order of a ~10 cm grid, 64 to a bucket), not a different kind of launch.
-      const int ng = ceil_div(int(nb), kTailGroup);
+      // from here on a round touches a dozen small buckets: all the remaining rounds in one launch of one
+      // workgroup (k_fps_tail; PYQSM_FPS_TAIL=0 keeps a launch per round). Measured, 1 M points -> 100 k
+      // samples: 5.3 us a round against 5.95 us (0.53 s against 0.595 s), same indices.
+      const int nb2 = ceil_div(N, kTailBucket), ng = ceil_div(nb2, kTailGroup);
       const char* te = getenv("PYQSM_FPS_TAIL");
-      if (late && ng <= kTailMaxGroups && te && te[0] == '1') {
+      if (late && ng <= kTailMaxGroups && !(te && te[0] == '0')) {
         const size_t lds = size_t(ng) * (sizeof(TailRec) + 48);
         static std::atomic<uint64_t> attr_set{0};
         const uint64_t bit = 1ull << (c->device & 63);
         if (!(attr_set.load(std::memory_order_acquire) & bit)) {
           PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fps_tail),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024));
           attr_set.fetch_or(bit, std::memory_order_release);
         }
-        const Far* cur = (s & 1) ? vb : va;  // the bucket records after sample s - 1
+        // the points in Morton order, 64 to a bucket, 64 buckets to a group: compact against the reach
         unsigned long long* d_dbg = nullptr;
-        if (getenv("PYQSM_FPS_TRACE")) PQ_TRY(c->arena.get(16, &d_dbg));
-        // buckets in Morton order of their cells: 64 consecutive ones are a compact blob
+        if (getenv("PYQSM_FPS_TRACE")) PQ_TRY(c->arena.get(8, &d_dbg));
         uint32_t* key;
-        int32_t* perm;
-        TailRec* trec;
-        double* tbox;
-        int2* tq;
-        PQ_TRY(c->arena.get(size_t(nb), &key));
-        PQ_TRY(c->arena.get(size_t(nb), &perm));
-        PQ_TRY(c->arena.get(size_t(nb), &trec));
-        PQ_TRY(c->arena.get(size_t(nb) * 6, &tbox));
-        PQ_TRY(c->arena.get(size_t(nb), &tq));
-        hipLaunchKernelGGL(k_fps_tail_key, dim3(ceil_div(nb, 256)), dim3(256), 0, c->stream, int(nb), g.nx, g.ny,
-                           static_cast<const int32_t*>(bstart), static_cast<const int32_t*>(g.cell_of), key, perm);
+        int32_t *perm, *t_id;
+        TailSoA rec;
+        double *t_x, *t_y, *t_z, *t_d;
+        PQ_TRY(c->arena.get(size_t(N), &key));
+        PQ_TRY(c->arena.get(size_t(N), &perm));
+        PQ_TRY(c->arena.get(size_t(N), &t_id));
+        PQ_TRY(c->arena.get(size_t(N), &t_x));
+        PQ_TRY(c->arena.get(size_t(N), &t_y));
+        PQ_TRY(c->arena.get(size_t(N), &t_z));
+        PQ_TRY(c->arena.get(size_t(N), &t_d));
+        PQ_TRY(c->arena.get(size_t(nb2), &rec.d));
+        PQ_TRY(c->arena.get(size_t(nb2), &rec.x));
+        PQ_TRY(c->arena.get(size_t(nb2), &rec.y));
+        PQ_TRY(c->arena.get(size_t(nb2), &rec.z));
+        PQ_TRY(c->arena.get(size_t(nb2), &rec.idx));
+        PQ_TRY(c->arena.get(size_t(nb2), &rec.pos));
+        for (int a = 0; a < 6; ++a) PQ_TRY(c->arena.get(size_t(nb2), &rec.box[a]));
+        hipLaunchKernelGGL(k_fps_tail_key, dim3(ceil_div(N, 256)), dim3(256), 0, c->stream, N,
+                           static_cast<const double*>(g.sx), static_cast<const double*>(g.sy),
+                           static_cast<const double*>(g.sz), mn[0], mn[1], mn[2], 1024.0 / ext, key, perm);
         PQ_HIP(hipGetLastError());
-        PQ_TRY(stable_sort_pairs_u32(c, &key, &perm, nb, 30));
-        hipLaunchKernelGGL(k_fps_tail_prep, dim3(ceil_div(nb, 256)), dim3(256), 0, c->stream, int(nb),
-                           static_cast<const int32_t*>(perm), static_cast<const int32_t*>(bstart),
-                           static_cast<const double*>(aabb), cur, static_cast<const double*>(g.sx),
-                           static_cast<const double*>(g.sy), static_cast<const double*>(g.sz), trec, tbox, tq);
-        hipLaunchKernelGGL(k_fps_tail, dim3(1), dim3(kTailThreads), lds, c->stream, s, S, int(nb), ng,
-                           static_cast<const int2*>(tq), static_cast<const double*>(tbox),
-                           static_cast<const int32_t*>(g.order), static_cast<const double*>(g.sx),
-                           static_cast<const double*>(g.sy), static_cast<const double*>(g.sz), dist, trec, d_out,
-                           d_dbg);
+        PQ_TRY(stable_sort_pairs_u32(c, &key, &perm, N, 30));
+        hipLaunchKernelGGL(k_fps_tail_points, dim3(ceil_div(N, 256)), dim3(256), 0, c->stream, N,
+                           static_cast<const int32_t*>(perm), static_cast<const double*>(g.sx),
+                           static_cast<const double*>(g.sy), static_cast<const double*>(g.sz),
+                           static_cast<const double*>(dist), static_cast<const int32_t*>(g.order), t_x, t_y, t_z, t_d, t_id);
+        hipLaunchKernelGGL(k_fps_tail_buckets, dim3(ceil_div(nb2, 4)), dim3(256), 0, c->stream, N, nb2,
+                           static_cast<const double*>(t_x), static_cast<const double*>(t_y),
+                           static_cast<const double*>(t_z), static_cast<const double*>(t_d),
+                           static_cast<const int32_t*>(t_id), rec);
+        hipLaunchKernelGGL(k_fps_tail, dim3(1), dim3(kTailThreads), lds, c->stream, s, S, N, nb2, ng, rec,
+                           static_cast<const int32_t*>(t_id), static_cast<const double*>(t_x),
+                           static_cast<const double*>(t_y), static_cast<const double*>(t_z), t_d, d_out, d_dbg);
+        PQ_HIP(hipGetLastError());
         if (d_dbg) {
-          unsigned long long h[16];
+          unsigned long long h[8];
           PQ_HIP(hipMemcpyAsync(h, d_dbg, sizeof(h), hipMemcpyDeviceToHost, c->stream));
           PQ_HIP(hipStreamSynchronize(c->stream));
           const double r = double(S - s);
@@ -777,8 +940,6 @@ static int fps_pruned(Ctx* c, const double* d_xyz, int N, int S, int start_index
                   "fold %.1f; groups in reach %.2f, buckets updated %.2f; shader clock %.0f MHz\n", h[0] / r, h[1] / r,
                   h[2] / r, h[3] / r, h[4] / r, h[5] / r, h[6] / r,
                   100.0 * double(h[7]) / double(h[0] + h[1] + h[2] + h[3] + h[4]));
-          fprintf(stderr, "  argmax in shader cycles: scan %.0f, wave fold %.0f, barrier %.0f, thread 0 %.0f, barrier %.0f\n",
-                  h[8] / r, h[9] / r, h[10] / r, h[11] / r, h[12] / r);
         }
         if (getenv("PYQSM_FPS_TRACE")) fprintf(stderr, "fps: rounds %d .. %d in one launch (%d groups)\n", s, S, ng);
         break;

@@ -72,10 +72,9 @@ def test_skeleton_to_qsm_radii(gpu):
 
 def test_fps_pruned_rounds_match_oracle_and_whole_cloud_rounds(gpu, monkeypatch):
     """From 65 536 points on, a round only touches the buckets the new sample can still improve
-    (fps.hip: k_fps_pruned); with PYQSM_FPS_TAIL=1, once the samples' reach is down to a cell or
-    two, all remaining rounds run inside ONE launch of one workgroup with a second level of 64-bucket
-    groups in LDS (k_fps_tail: built in round 3, measured slower than a launch per round — one CU's
-    bandwidth — and therefore off by default). Same indices as the NumPy restatement (start index not 0), and — at a
+    (fps.hip: k_fps_pruned), and once the samples' reach is down to a cell or two all remaining
+    rounds run inside ONE launch of one workgroup on Morton-ordered 64-point buckets with two levels of
+    groups in LDS (k_fps_tail; PYQSM_FPS_TAIL=0 keeps a launch per round). Same indices as the NumPy restatement (start index not 0), and — at a
     size the restatement cannot reach — as the whole-cloud rounds (PYQSM_FPS_PRUNE=0), including a
     cloud where a third of the points are exact duplicates and the sampling runs until every
     distance is zero."""
@@ -88,7 +87,7 @@ def test_fps_pruned_rounds_match_oracle_and_whole_cloud_rounds(gpu, monkeypatch)
     a = hip.fps(Q, 40_000, 7, device=gpu)
     R = np.concatenate([P[:50_000], P[:50_000][::-1][:30_000]])                      # 30 000 exact copies
     b = hip.fps(R, len(R), 0, device=gpu)                                            # down to distance zero
-    monkeypatch.setenv("PYQSM_FPS_TAIL", "1")             # the late rounds inside one launch (k_fps_tail)
+    monkeypatch.setenv("PYQSM_FPS_TAIL", "0")             # a launch per round to the end (round 2's path)
     assert np.array_equal(a, hip.fps(Q, 40_000, 7, device=gpu))
     assert np.array_equal(b, hip.fps(R, len(R), 0, device=gpu))
     monkeypatch.delenv("PYQSM_FPS_TAIL")

@@ -10,7 +10,7 @@ P = synth.forest(n)
 hip.fps(P, 2000, 0)
 ref = None
 for rnd in range(2):
-    for name, env in (("tail", {"PYQSM_FPS_TAIL": "1"}), ("launches", {})):
+    for name, env in (("tail", {}), ("launches", {"PYQSM_FPS_TAIL": "0"})):
         os.environ.pop("PYQSM_FPS_TAIL", None)
         os.environ.update(env)
         t = time.perf_counter()
@@ -22,7 +22,7 @@ for rnd in range(2):
 # a contracted cloud (what extract_topology samples): points pulled towards the stems
 Q = P.copy()
 Q[:, :2] = np.round(Q[:, :2] / 10.0) * 10.0 + (Q[:, :2] - np.round(Q[:, :2] / 10.0) * 10.0) * 0.05
-for name, env in (("tail", {"PYQSM_FPS_TAIL": "1"}), ("launches", {})):
+for name, env in (("tail", {}), ("launches", {"PYQSM_FPS_TAIL": "0"})):
     os.environ.pop("PYQSM_FPS_TAIL", None)
     os.environ.update(env)
     t = time.perf_counter()
