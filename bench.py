@@ -597,16 +597,25 @@ def main():
         hip.fps(pts, 2000, 0, dev)
         t0 = time.perf_counter()
         picked = hip.fps(pts, s_fps, 0, dev)
+        t_tail = time.perf_counter() - t0
+        os.environ["PYQSM_FPS_TAIL"] = "0"
+        t0 = time.perf_counter()
+        launched = hip.fps(pts, s_fps, 0, dev)
         t_pruned = time.perf_counter() - t0
+        del os.environ["PYQSM_FPS_TAIL"]
         os.environ["PYQSM_FPS_PRUNE"] = "0"
         t0 = time.perf_counter()
         whole = hip.fps(pts, s_fps, 0, dev)
         t_whole = time.perf_counter() - t0
         del os.environ["PYQSM_FPS_PRUNE"]
-        out["fps"] = {"points": n, "samples": s_fps, "s_pruned_rounds": t_pruned, "s_whole_cloud_rounds": t_whole,
-                      "us_per_sample": t_pruned / s_fps * 1e6,
-                      "same_indices": bool(np.array_equal(picked, whole)), "dtype": "f64",
-                      "note": "host buffers in and out; whole-cloud rounds move 32 B per point and sample"}
+        out["fps"] = {"points": n, "samples": s_fps, "s": t_tail, "s_launch_per_round": t_pruned,
+                      "s_whole_cloud_rounds": t_whole, "us_per_sample": t_tail / s_fps * 1e6,
+                      "same_indices": bool(np.array_equal(picked, whole) and np.array_equal(picked, launched)),
+                      "dtype": "f64",
+                      "note": "host buffers in and out; default = pruned rounds as launches until the samples' reach is "
+                              "below three cells, then all remaining rounds inside one launch of one workgroup "
+                              "(k_fps_tail); s_launch_per_round = PYQSM_FPS_TAIL=0; whole-cloud rounds move 32 B per "
+                              "point and sample"}
 
     # ------------------------------------------------------------- config 5: the whole pipeline
     if not args.no_config5 and not args.no_skeleton and world == 1:
