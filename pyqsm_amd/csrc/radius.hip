@@ -61,11 +61,10 @@ __device__ __forceinline__ void clamped_cell(const RGrid& g, double x, double y,
 
 // MODE 0: count of source points with d2 < r2.  MODE 1: count with d2 <= tau.
 // MODE 2: mark every source point with d2 < bound (bound = r2, or tau plus ties).
-template <int MODE>
+template <int MODE, class CO>
 __device__ __forceinline__ int walk(const RGrid& g, const int32_t* __restrict__ start,
                                     const int32_t* __restrict__ order,
-                                    const double* __restrict__ sx, const double* __restrict__ sy,
-                                    const double* __restrict__ sz, double x, double y, double z,
+                                    CO co, double x, double y, double z,
                                     double r2, double tau, int budget, uint8_t* __restrict__ mark,
                                     int32_t* __restrict__ lab_out = nullptr, int lab = 0) {
   // The query's cell, clamped into the grid the way the sources were binned (grid.hip: cell_index):
@@ -84,7 +83,7 @@ __device__ __forceinline__ int walk(const RGrid& g, const int32_t* __restrict__ 
       const int x0 = cx - 1 < 0 ? 0 : cx - 1, x1 = cx + 1 >= g.nx ? g.nx - 1 : cx + 1;
       const int row = (zz * g.ny + yy) * g.nx;
       for (int q = start[row + x0]; q < start[row + x1 + 1]; ++q) {
-        const double d = sqd(x, y, z, sx[q], sy[q], sz[q]);
+        const double d = co.d2(q, x, y, z);
         if (MODE == 0) cnt += d < r2;
         if (MODE == 1) cnt += d < r2 && d <= tau;
         if (MODE == 2) {
@@ -104,12 +103,11 @@ __device__ __forceinline__ int walk(const RGrid& g, const int32_t* __restrict__ 
   return cnt;
 }
 
+template <class CO>
 __global__ __launch_bounds__(256) void k_radius_mark(int m, const double* __restrict__ qry,
                                                      RGrid g, const int32_t* __restrict__ start,
                                                      const int32_t* __restrict__ order,
-                                                     const double* __restrict__ sx,
-                                                     const double* __restrict__ sy,
-                                                     const double* __restrict__ sz, double r2,
+                                                     CO co, double r2,
                                                      int k, uint8_t* __restrict__ mark,
                                                      int32_t* __restrict__ counts,
                                                      const int32_t* __restrict__ qlab /*may be null*/,
@@ -119,7 +117,7 @@ __global__ __launch_bounds__(256) void k_radius_mark(int m, const double* __rest
   const double x = qry[3 * i], y = qry[3 * i + 1], z = qry[3 * i + 2];
   int32_t* lo_ = qlab ? lab_out : nullptr;
   const int lab = qlab ? qlab[i] : 0;
-  const int c = walk<0>(g, start, order, sx, sy, sz, x, y, z, r2, 0.0, 0, mark);
+  const int c = walk<0>(g, start, order, co, x, y, z, r2, 0.0, 0, mark);
   counts[i] = c < k ? c : k;
   if (c == 0) return;
   double tau = __builtin_inf();
@@ -130,16 +128,16 @@ __global__ __launch_bounds__(256) void k_radius_mark(int m, const double* __rest
     while (lo < hi) {  // smallest t with #{d2 <= t} >= k
       const unsigned long long mid = lo + ((hi - lo) >> 1);
       const double t = __longlong_as_double((long long)mid);
-      if (walk<1>(g, start, order, sx, sy, sz, x, y, z, r2, t, 0, mark) >= k) hi = mid;
+      if (walk<1>(g, start, order, co, x, y, z, r2, t, 0, mark) >= k) hi = mid;
       else lo = mid + 1;
     }
     tau = __longlong_as_double((long long)lo);
     // points strictly below tau are all taken; ties at tau fill what is left of k
     const double below = lo == 0 ? -1.0 : __longlong_as_double((long long)(lo - 1));
-    const int n_below = lo == 0 ? 0 : walk<1>(g, start, order, sx, sy, sz, x, y, z, r2, below, 0, mark);
+    const int n_below = lo == 0 ? 0 : walk<1>(g, start, order, co, x, y, z, r2, below, 0, mark);
     budget = k - n_below;
   }
-  (void)walk<2>(g, start, order, sx, sy, sz, x, y, z, r2, tau, budget, mark, lo_, lab);
+  (void)walk<2>(g, start, order, co, x, y, z, r2, tau, budget, mark, lo_, lab);
 }
 
 
@@ -172,12 +170,11 @@ __device__ __forceinline__ bool query_runs(const RGrid& g, const int32_t* __rest
   return true;
 }
 
+template <class CO>
 __global__ __launch_bounds__(128) void k_radius_knn(int m, const double* __restrict__ qry, RGrid g,
                                                     const int32_t* __restrict__ start,
                                                     const int32_t* __restrict__ order,
-                                                    const double* __restrict__ sx,
-                                                    const double* __restrict__ sy,
-                                                    const double* __restrict__ sz, double r2, int k,
+                                                    CO co, double r2, int k,
                                                     int n_src, int64_t* __restrict__ out_idx,
                                                     double* __restrict__ out_dist) {
   __shared__ double sd[2][kKnnCap];
@@ -196,7 +193,7 @@ __global__ __launch_bounds__(128) void k_radius_knn(int m, const double* __restr
         const int q = base + lane;
         bool in = false;
         if (q < rr.qe[r]) {
-          const double d = sqd(x, y, z, sx[q], sy[q], sz[q]);
+          const double d = co.d2(q, x, y, z);
           in = d < r2 && d <= tau;
         }
         cnt += __popcll(__ballot(in));
@@ -227,7 +224,7 @@ __global__ __launch_bounds__(128) void k_radius_knn(int m, const double* __restr
         double d = 0.0;
         bool below = false, tie = false;
         if (q < rr.qe[r]) {
-          d = sqd(x, y, z, sx[q], sy[q], sz[q]);
+          d = co.d2(q, x, y, z);
           below = d < r2 && d < tau;
           tie = d < r2 && d == tau;
         }
@@ -284,10 +281,11 @@ __global__ __launch_bounds__(128) void k_radius_knn(int m, const double* __restr
 // of the radius any more — every doubling of the edge is 8x the points per cell).
 static int source_grid(Ctx* c, const double* d_src, int64_t n, double radius, DevGrid* g) {
   double box[6];
-  PQ_TRY(cloud_bbox(c, d_src, n, box, box + 3));
+  bool all_f32 = false;  // every source coordinate fp32-representable: 16-byte fp32 records (grid.hpp: on_coords)
+  PQ_TRY(cloud_bbox(c, d_src, n, box, box + 3, &all_f32));
   int64_t outside = 0;
   PQ_TRY(robust_box(c, d_src, n, int(std::min<int64_t>(8192, std::max<int64_t>(256, n / 256))), box, &outside));
-  return build_grid(c, d_src, n, radius * (1.0 + 1.0 / 1048576.0), int64_t(1) << 28, g, box);
+  return build_grid(c, d_src, n, radius * (1.0 + 1.0 / 1048576.0), int64_t(1) << 28, g, box, all_f32);
 }
 
 }  // namespace pyqsm
@@ -367,9 +365,11 @@ int pyqsm_radius_mark(const double* src, int64_t n, const double* qry, int64_t m
   RGrid rg{g.minx, g.miny, g.minz, g.inv_cell, g.nx, g.ny, g.nz};
   {
     ProfScope ps(c, "radius_mark");
-    hipLaunchKernelGGL(k_radius_mark, dim3(ceil_div(m, 256)), dim3(256), 0, c->stream, int(m), d_qry,
-                       rg, g.start, g.order, g.sx, g.sy, g.sz, radius * radius, k_cap, d_mark,
-                       d_counts, static_cast<const int32_t*>(nullptr), static_cast<int32_t*>(nullptr));
+    on_coords(g, [&](auto co) {
+      hipLaunchKernelGGL(k_radius_mark<decltype(co)>, dim3(ceil_div(m, 256)), dim3(256), 0, c->stream, int(m), d_qry,
+                         rg, g.start, g.order, co, radius * radius, k_cap, d_mark, d_counts,
+                         static_cast<const int32_t*>(nullptr), static_cast<int32_t*>(nullptr));
+    });
     PQ_HIP(hipGetLastError());
   }
   PQ_HIP(hipMemcpyAsync(mark, d_mark, size_t(n), hipMemcpyDeviceToHost, c->stream));
@@ -412,8 +412,10 @@ int pyqsm_radius_knn(const double* src, int64_t n, const double* qry, int64_t m,
   RGrid rg{g.minx, g.miny, g.minz, g.inv_cell, g.nx, g.ny, g.nz};
   {
     ProfScope ps(c, "radius_knn");
-    hipLaunchKernelGGL(k_radius_knn, dim3(ceil_div(m, 2)), dim3(128), 0, c->stream, int(m), d_qry, rg,
-                       g.start, g.order, g.sx, g.sy, g.sz, radius * radius, k, int(n), d_idx, d_dist);
+    on_coords(g, [&](auto co) {
+      hipLaunchKernelGGL(k_radius_knn<decltype(co)>, dim3(ceil_div(m, 2)), dim3(128), 0, c->stream, int(m), d_qry, rg,
+                         g.start, g.order, co, radius * radius, k, int(n), d_idx, d_dist);
+    });
     PQ_HIP(hipGetLastError());
   }
   PQ_HIP(hipMemcpyAsync(idx, d_idx, size_t(m) * k * 8, hipMemcpyDeviceToHost, c->stream));
@@ -460,9 +462,10 @@ int pyqsm_radius_label(const double* src, int64_t n, const double* qry, int64_t 
   RGrid rg{g.minx, g.miny, g.minz, g.inv_cell, g.nx, g.ny, g.nz};
   {
     ProfScope ps(c, "radius_label");
-    hipLaunchKernelGGL(k_radius_mark, dim3(ceil_div(m, 256)), dim3(256), 0, c->stream, int(m), d_qry,
-                       rg, g.start, g.order, g.sx, g.sy, g.sz, radius * radius, k_cap, d_mark,
-                       d_counts, d_qlab, d_lab);
+    on_coords(g, [&](auto co) {
+      hipLaunchKernelGGL(k_radius_mark<decltype(co)>, dim3(ceil_div(m, 256)), dim3(256), 0, c->stream, int(m), d_qry,
+                         rg, g.start, g.order, co, radius * radius, k_cap, d_mark, d_counts, d_qlab, d_lab);
+    });
     PQ_HIP(hipGetLastError());
   }
   PQ_HIP(hipMemcpyAsync(label, d_lab, size_t(n) * 4, hipMemcpyDeviceToHost, c->stream));
