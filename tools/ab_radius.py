@@ -10,8 +10,10 @@ rng = np.random.default_rng(0)
 Q = P[rng.choice(n, 100_000, replace=False)] + rng.normal(0, 0.01, (100_000, 3))
 ref = {}
 for rnd in range(2):
-    for name, env in (("fp32 records", {}), ("fp64 arrays", {"PYQSM_COORD_F32": "0"})):
+    for name, env in (("sorted+fp32", {}), ("sorted fp64", {"PYQSM_COORD_F32": "0"}),
+                      ("caller order", {"PYQSM_RADIUS_SORT": "0"})):
         os.environ.pop("PYQSM_COORD_F32", None)
+        os.environ.pop("PYQSM_RADIUS_SORT", None)
         os.environ.update(env)
         out = {}
         for what, fn in (("radius_mark", lambda: hip.radius_mark(P, Q, 0.1, 200)),
