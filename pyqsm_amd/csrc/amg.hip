@@ -33,6 +33,7 @@
 #include "grid.hpp"
 #include "sparse.hpp"
 
+#include <atomic>
 #include <cmath>
 #include <type_traits>
 
@@ -724,6 +725,45 @@ __global__ __launch_bounds__(256) void k_scale(int n, const float* __restrict__ 
   if (i < n) scale_row(i, dinv, b, x);
 }
 
+// The tail sweeps of a coarsest level that is too big for a dense solve, in ONE launch of one
+// workgroup (round 3): x = Dinv b and kTailSweeps l1-Jacobi sweeps cost nine launches of ~6.4 us
+// each (57 us of a 212 us multigrid-CG iteration on the first contractions, where the hierarchy
+// stops after two coarsenings at a few thousand unknowns). Here b and the two iterates live in
+// LDS, every thread keeps its rows for all sweeps (so the row's entries come out of its L1 from
+// the second sweep on), and a sweep is a workgroup barrier instead of a launch. Same row
+// function, same order of operations: the result has the bits of the launches.
+static constexpr int kFusedTailThreads = 1024;
+static constexpr int kFusedTailMaxRows = 3072;  // three float4 vectors per row in LDS: 144 KB
+__global__ __launch_bounds__(kFusedTailThreads) void k_tail_sweeps(int n, int sweeps,
+                                                                  const int32_t* __restrict__ indptr,
+                                                                  const int32_t* __restrict__ indices,
+                                                                  const float* __restrict__ vals,
+                                                                  const float* __restrict__ dinv,
+                                                                  const float* __restrict__ b,
+                                                                  float* __restrict__ x_out) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* lb = lds;                               // [n] float4
+  float* xa = lds + size_t(n) * kVecStride;      // [n] float4
+  float* xb = xa + size_t(n) * kVecStride;       // [n] float4
+  for (int i = threadIdx.x; i < n; i += kFusedTailThreads) {
+    const float4 bi = ld4(b, i);
+    st4(lb, i, bi.x, bi.y, bi.z);
+    const float d = dinv[i];
+    st4(xb, i, d * bi.x, d * bi.y, d * bi.z);    // scale_row
+  }
+  __syncthreads();
+  for (int s = 0; s < sweeps; s += 2) {
+    for (int i = threadIdx.x; i < n; i += kFusedTailThreads) sweep_row(i, indptr, indices, vals, dinv, lb, xb, xa);
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += kFusedTailThreads) sweep_row(i, indptr, indices, vals, dinv, lb, xa, xb);
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < n; i += kFusedTailThreads) {
+    const float4 v = ld4(xb, i);
+    st4(x_out, i, v.x, v.y, v.z);
+  }
+}
+
 // x = Ainv * b on the coarsest level (nc <= kCoarseMax) by the first 3 * nc threads of the block
 // (every thread of the block calls it): thread (i, k) adds up row i for column k in four
 // interleaved chains; the inverse is stored transposed, so that a wave's loads are contiguous
@@ -1040,6 +1080,24 @@ void amg_destroy(AmgHierarchy* h) { delete h; }
 
 int amg_levels(const AmgHierarchy* h) { return h ? int(h->lv.size()) : 0; }
 
+static bool fused_tail_enabled() {  // PYQSM_AMG_FUSED_TAIL=0: a launch per tail sweep (A/B comparisons)
+  static const bool v = [] {
+    const char* e = getenv("PYQSM_AMG_FUSED_TAIL");
+    return !(e && e[0] == '0');
+  }();
+  return v;
+}
+static int allow_fused_tail_lds(Ctx* c) {
+  static std::atomic<uint64_t> attr_set{0};
+  const uint64_t bit = 1ull << (c->device & 63);
+  if (!(attr_set.load(std::memory_order_acquire) & bit)) {
+    PQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tail_sweeps), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               kFusedTailMaxRows * kVecStride * 4 * 3));
+    attr_set.fetch_or(bit, std::memory_order_release);
+  }
+  return 0;
+}
+
 // TV = double: fp64 right-hand side and result (the cycle converts the former);
 // TV = float: both fp32 (the fp32 CG of lbc.hip), no conversion pass.
 template <typename TV>
@@ -1062,6 +1120,10 @@ static int vcycle_impl(Ctx* c, AmgHierarchy* H, const TV* b, TV* x, double* dot)
     if (l == nl - 1) {  // (never level 0: hierarchies with a single level are not used)
       if (H->dense_inv) {
         hipLaunchKernelGGL(k_dense_solve, dim3(1), dim3(3 * kCoarseMax), 0, c->stream, L.n, H->dense_inv, bl, L.xb);
+      } else if (L.n <= kFusedTailMaxRows && fused_tail_enabled()) {  // the same sweeps in one launch
+        PQ_TRY(allow_fused_tail_lds(c));
+        hipLaunchKernelGGL(k_tail_sweeps, dim3(1), dim3(kFusedTailThreads), size_t(L.n) * kVecStride * 4 * 3, c->stream,
+                           L.n, kTailSweeps, L.A.indptr, L.A.indices, L.valsf, L.dinvf, bl, L.xb);
       } else {  // kTailSweeps (even) l1-Jacobi sweeps, ending in xb
         hipLaunchKernelGGL(k_scale, g, blk, 0, c->stream, L.n, L.dinvf, bl, L.xb);
         for (int s = 0; s < kTailSweeps; s += 2) {
