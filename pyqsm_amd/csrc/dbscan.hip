@@ -368,11 +368,13 @@ __global__ __launch_bounds__(256) void k_hook_sub(const int4* __restrict__ list,
                                                   int* __restrict__ parent,
                                                   int32_t* __restrict__ nbr) {
   const int m = *m_ptr;
-  const int s0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * kSubPerWave;
-  if (s0 >= m) return;  // wave-uniform
   const int k = threadIdx.x & 63;
   const int o_dx = k < 62 ? kSubOffsets[k][0] : 0, o_dy = k < 62 ? kSubOffsets[k][1] : 0,
             o_dz = k < 62 ? kSubOffsets[k][2] : 0;
+  // resident waves stride over the list (wave-uniform bounds): the launch is sized for the chip, not
+  // for the upper bound n of m — four waves in five of such a grid found nothing to do and still
+  // had to be started (SQ_WAVES 250 k per million points for 49 k with work)
+  for (int s0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * kSubPerWave; s0 < m; s0 += gridDim.x * 4 * kSubPerWave) {
   // the dependent loads (list -> start -> rec) of the wave's sub-cells are issued side by side.
   // (What these kernels cost is the number of cache LINES their gathers touch — one per
   // neighbouring cell and table, taken by the L1 a line at a time. Dropping the second gather
@@ -442,6 +444,10 @@ __global__ __launch_bounds__(256) void k_hook_sub(const int4* __restrict__ list,
       if (found && k == 0) parent[p] = parent[rb];
     }
   }
+  // (Taking the wave's sub-cells in rounds — one candidate of each per round, their gathers issued
+  // side by side, idle lanes reading the sub-cell's own representative — was SLOWER, 104 against 82 us
+  // per million points: the depth of one wave's dependent chain is not what bounds the pass.)
+  }
 }
 
 // Pass 2: a WAVE per kSubPerWave sub-cells with core points, over the same pairs (sub-cell, neighbour at
@@ -460,9 +466,8 @@ __global__ __launch_bounds__(256) void k_union_sub(const int4* __restrict__ list
                                                    const int4* __restrict__ rec, CO co, double r2,
                                                    const uint8_t* __restrict__ core, int* parent) {
   const int m = *m_ptr;
-  const int s0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * kSubPerWave;
-  if (s0 >= m) return;  // wave-uniform
   const int k = threadIdx.x & 63;
+  for (int s0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * kSubPerWave; s0 < m; s0 += gridDim.x * 4 * kSubPerWave) {
   int rep2[kSubPerWave];
   int4 me[kSubPerWave];
 #pragma unroll
@@ -512,6 +517,7 @@ __global__ __launch_bounds__(256) void k_union_sub(const int4* __restrict__ list
       }
       if (found && k == 0) unite(parent, p, rb);
     }
+  }
   }
 }
 
@@ -794,13 +800,26 @@ static int dbscan_device(Ctx* c, const double* xyz, int64_t n, double eps, int32
         rows = m;
       }
       if (rows > 0) {
-        const dim3 gw(ceil_div(rows, 4 * kSubPerWaveDefault)), gl(ceil_div(rows, 256));
+        // the two wave-per-sub-cells passes: at most the waves the chip holds at their occupancy (8 per
+        // SIMD), striding over the list
+        // the two wave-per-sub-cells passes: resident waves striding over the list, 16 (hook) and 32
+        // (union) blocks per CU — measured against a block per 16 rows of the bound n: hook 91 -> 82 us,
+        // union 68.5 -> 64 us per million points (PYQSM_UNION_BLOCKS_PER_CU=<hook>,<union>; 0 = the bound)
+        int per_cu[2] = {16, 32};
+        if (const char* e_cu = getenv("PYQSM_UNION_BLOCKS_PER_CU")) {
+          per_cu[0] = per_cu[1] = atoi(e_cu);
+          if (const char* comma = strchr(e_cu, ',')) per_cu[1] = atoi(comma + 1);
+        }
+        const int64_t full = ceil_div(rows, 4 * kSubPerWaveDefault);
+        const dim3 gh(per_cu[0] > 0 ? std::min<int64_t>(full, int64_t(c->cu_count) * per_cu[0]) : full),
+            gu(per_cu[1] > 0 ? std::min<int64_t>(full, int64_t(c->cu_count) * per_cu[1]) : full),
+            gl(ceil_div(rows, 256));
         int32_t* nbr;  // [m][64] representatives of the neighbour sub-cells pass 1 resolved
         PQ_TRY(c->arena.get(size_t(rows) * 64, &nbr));
         {
           ProfScope pk(c, "k_hook_sub");
           on_coords(g, [&](auto co) {
-            hipLaunchKernelGGL((k_hook_sub<kSubPerWaveDefault, decltype(co)>), gw, block, 0, c->stream, list,
+            hipLaunchKernelGGL((k_hook_sub<kSubPerWaveDefault, decltype(co)>), gh, block, 0, c->stream, list,
                                list_cnt, g.nx, g.ny, g.start, sub.rec, co, r2, core, parent, nbr);
           });
         }
@@ -810,7 +829,7 @@ static int dbscan_device(Ctx* c, const double* xyz, int64_t n, double eps, int32
         {
           ProfScope pk(c, "k_union_sub");
           on_coords(g, [&](auto co) {
-            hipLaunchKernelGGL((k_union_sub<kSubPerWaveDefault, decltype(co)>), gw, block, 0, c->stream, list,
+            hipLaunchKernelGGL((k_union_sub<kSubPerWaveDefault, decltype(co)>), gu, block, 0, c->stream, list,
                                list_cnt, nbr, sub.sub_of, sub.rec, co, r2, core, parent);
           });
         }

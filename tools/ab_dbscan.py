@@ -7,13 +7,16 @@ from pyqsm_amd import hip, synth, _lib
 _lib.require_gpu(0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 variants = [("bucketed+f32", {}), ("bucketed f64", {"PYQSM_COORD_F32": "0"}), ("atomic  f64", {"PYQSM_DBSCAN_BIN": "atomic"})]
+if len(sys.argv) > 2 and sys.argv[2] == "union":   # grid of the two wave-per-sub-cells passes
+    variants = [("16,32 per CU", {}), ("bound grid", {"PYQSM_UNION_BLOCKS_PER_CU": "0"}), ("8,8 per CU", {"PYQSM_UNION_BLOCKS_PER_CU": "8"}),
+                ("16,64 per CU", {"PYQSM_UNION_BLOCKS_PER_CU": "16,64"})]
 P = synth.forest(n)
 d_xyz = hip.DeviceBuffer.from_array(P)
 d_lab = hip.DeviceBuffer(n * 8); d_core = hip.DeviceBuffer(n)
 ref = None
 for rnd in range(3):
     for name, env in variants:
-        for k in ("PYQSM_DBSCAN_BIN", "PYQSM_COORD_F32"):
+        for k in ("PYQSM_DBSCAN_BIN", "PYQSM_COORD_F32", "PYQSM_UNION_BLOCKS_PER_CU"):
             os.environ.pop(k, None)
         os.environ.update(env)
         for _ in range(3):
