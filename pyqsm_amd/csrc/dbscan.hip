@@ -18,6 +18,7 @@
 // d2 = ((dx*dx) + dy*dy) + dz*dz with separately rounded products, compared
 // with fl(eps*eps). The library is compiled with -ffp-contract=off.
 #include "grid.hpp"
+#include <vector>
 
 namespace pyqsm {
 
@@ -341,15 +342,18 @@ static constexpr int kSubPerWaveDefault = 4;
 // Full path compression for the listed representatives (plain accesses: the kernel
 // boundary makes the unions of the previous launch visible, and any value another lane
 // writes meanwhile is an ancestor too).
+// Two launches: the first moves every pointer `max_steps` links up (a hundred and more dependent
+// loads per thread, all threads starting together, was 35 us per million points), the second then
+// reaches the root in depth / max_steps hops over the pointers the first one left.
 __global__ __launch_bounds__(256) void k_flatten_reps(const int4* __restrict__ list,
                                                       const int32_t* __restrict__ m_ptr,
-                                                      int* __restrict__ parent) {
+                                                      int* __restrict__ parent, int max_steps) {
   const int m = *m_ptr;  // number of listed sub-cells, left on the device by k_sub_rep
   int s = blockIdx.x * 256 + threadIdx.x;
   if (s >= m) return;
   const int p = list[s].x;
-  int r = p;
-  for (int nx = parent[r]; nx != r; nx = parent[r]) r = nx;
+  int r = p, steps = 0;
+  for (int nx = parent[r]; nx != r && steps < max_steps; nx = parent[r], ++steps) r = nx;
   parent[p] = r;
 }
 
@@ -441,6 +445,10 @@ __global__ __launch_bounds__(256) void k_hook_sub(const int4* __restrict__ list,
       // listed in spatial order, the smaller neighbour's wave has usually finished, and what
       // it points to is an ancestor still smaller than this sub-cell (no cycles). Chains come
       // out a few links long instead of as long as a trunk is tall in sub-cells.
+      // (The chains are nevertheless long — 80 % of the benchmark forest's sub-cells sit more than 64
+      // links from their root, PYQSM_DBSCAN_TRACE prints the histogram: a third of the list is in flight
+      // at once, so most neighbours have not hooked yet when their pointer is read, and agent-scope
+      // accesses here change nothing. k_flatten_reps deals with them in two passes.)
       if (found && k == 0) parent[p] = parent[rb];
     }
   }
@@ -823,7 +831,36 @@ static int dbscan_device(Ctx* c, const double* xyz, int64_t n, double eps, int32
                                list_cnt, g.nx, g.ny, g.start, sub.rec, co, r2, core, parent, nbr);
           });
         }
-        hipLaunchKernelGGL(k_flatten_reps, gl, block, 0, c->stream, list, list_cnt, parent);
+        if (getenv("PYQSM_DBSCAN_TRACE")) {  // how deep are the chains the hook pass leaves?
+          int32_t m = 0;
+          PQ_HIP(hipMemcpyAsync(&m, list_cnt, 4, hipMemcpyDeviceToHost, c->stream));
+          PQ_HIP(hipStreamSynchronize(c->stream));
+          std::vector<int32_t> hp(static_cast<size_t>(n), 0);
+          std::vector<int4> hl(static_cast<size_t>(m), make_int4(0, 0, 0, 0));
+          PQ_HIP(hipMemcpy(hp.data(), parent, size_t(n) * 4, hipMemcpyDeviceToHost));
+          PQ_HIP(hipMemcpy(hl.data(), list, size_t(m) * 16, hipMemcpyDeviceToHost));
+          std::vector<int64_t> hist(66, 0);
+          int64_t roots = 0;
+          for (int32_t s2 = 0; s2 < m; ++s2) {
+            int d = 0, r = hl[size_t(s2)].x;
+            while (hp[size_t(r)] != r && d < 65) {
+              r = hp[size_t(r)];
+              ++d;
+            }
+            hist[size_t(d)]++;
+            roots += d == 0;
+          }
+          fprintf(stderr, "hook pass: %d sub-cells, %lld roots; chain depth histogram:", m, (long long)roots);
+          for (int d = 0; d < 66; ++d)
+            if (hist[size_t(d)]) fprintf(stderr, " %d:%lld", d, (long long)hist[size_t(d)]);
+          fprintf(stderr, "\n");
+        }
+        static const int jump = [] {  // PYQSM_FLATTEN_JUMP: links of the first pass (0: one pass, the earlier form)
+          const char* e = getenv("PYQSM_FLATTEN_JUMP");
+          return e ? atoi(e) : 12;
+        }();
+        if (jump > 0) hipLaunchKernelGGL(k_flatten_reps, gl, block, 0, c->stream, list, list_cnt, parent, jump);
+        hipLaunchKernelGGL(k_flatten_reps, gl, block, 0, c->stream, list, list_cnt, parent, 0x7fffffff);
         // what is left: joining the few trees per cluster. Almost every pair of neighbours
         // now shows the same root through two plain loads.
         {

@@ -1326,6 +1326,15 @@ int laplacian_device(Ctx* c, const double* d_xyz, int64_t n, const int64_t* seg_
       m = hc[0];
       if (getenv("PYQSM_LBC_TRACE")) fprintf(stderr, "flip round %d list %d flips(last) %d\n", round, hc[0], hc[1]);
     }
+    if (getenv("PYQSM_LBC_TRACE")) {  // the rounds' own counters: list length going in, flips made
+      std::vector<int32_t> hcnt(size_t(kMaxFlipRounds + 2) * 2);
+      PQ_HIP(hipMemcpyAsync(hcnt.data(), d_cnt, hcnt.size() * 4, hipMemcpyDeviceToHost, c->stream));
+      PQ_HIP(hipStreamSynchronize(c->stream));
+      fprintf(stderr, "flip rounds of a cover of %d faces (list, flips):", F);
+      for (int r = 0; r < kMaxFlipRounds && hcnt[2 * size_t(r)] > 0; ++r)
+        fprintf(stderr, " %d:%d", hcnt[2 * size_t(r)], hcnt[2 * size_t(r) + 3]);
+      fprintf(stderr, "\n");
+    }
     hipLaunchKernelGGL(k_cover_vcount, gf, blk, 0, c->stream, F, d_fv, d_vcount);
   }
   PQ_TRY(exclusive_scan_i32(c, d_vcount, n + 1));  // row_start of the contributions
