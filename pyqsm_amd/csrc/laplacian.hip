@@ -616,6 +616,18 @@ __device__ __host__ inline double flipped_length(double lab, double lbk, double 
   return sqrt(dx * dx + dy * dy);
 }
 
+// Is the edge of length lab between the triangles (lab, lbk, lka) and (lab, lal, llb) to be flipped:
+// not Delaunay by more than the tolerance, and both triangles of the flipped quad proper.
+__device__ __host__ inline bool flip_wanted(double lab, double lbk, double lka, double lal, double llb,
+                                            double* lkl_out) {
+  const double sum = cot_opposite(lab, lbk, lka) + cot_opposite(lab, lal, llb);
+  if (!(sum < -kDelaunayTol)) return false;
+  const double lkl = flipped_length(lab, lbk, lka, lal, llb);
+  if (!(heron_area(lal, lkl, lka) > 0.0) || !(heron_area(lbk, lkl, llb) > 0.0)) return false;
+  *lkl_out = lkl;
+  return true;
+}
+
 struct FlipInfo {
   int f, c, g, d;
   double lab, lbk, lka, lal, llb, lkl;
@@ -633,13 +645,23 @@ __device__ __host__ inline bool flip_candidate(int h, const double* fl, const in
   const double lab = fl[3 * size_t(f) + c], lbk = fl[3 * size_t(f) + nx3(c)],
                lka = fl[3 * size_t(f) + pv3(c)];
   const double lal = fl[3 * size_t(g) + nx3(d)], llb = fl[3 * size_t(g) + pv3(d)];
-  const double sum = cot_opposite(lab, lbk, lka) + cot_opposite(lab, lal, llb);
-  if (!(sum < -kDelaunayTol)) return false;
-  const double lkl = flipped_length(lab, lbk, lka, lal, llb);
-  // both new triangles must be proper
-  if (!(heron_area(lal, lkl, lka) > 0.0) || !(heron_area(lbk, lkl, llb) > 0.0)) return false;
+  double lkl;
+  if (!flip_wanted(lab, lbk, lka, lal, llb, &lkl)) return false;
   *o = FlipInfo{f, c, g, d, lab, lbk, lka, lal, llb, lkl};
   return true;
+}
+
+// The same question for an outer edge of a quad that THIS thread has just flipped, asked with the
+// new face's side lengths still in registers (own[slot]) and only the face on the other side read
+// from memory: half-edge h_own of the new face, glued to h_nbr. As flip_candidate does, the edge is
+// looked at from the side of the smaller id.
+__device__ __forceinline__ bool outer_edge_wanted(int h_own, const double own[3], int h_nbr,
+                                                  const double* __restrict__ fl) {
+  const int so = h_own % 3, fb = h_nbr / 3, sb = h_nbr % 3;
+  const double n0 = fl[3 * size_t(fb) + sb], n1 = fl[3 * size_t(fb) + nx3(sb)], n2 = fl[3 * size_t(fb) + pv3(sb)];
+  double lkl;
+  return h_own < h_nbr ? flip_wanted(own[so], own[nx3(so)], own[pv3(so)], n1, n2, &lkl)
+                       : flip_wanted(n0, n1, n2, own[nx3(so)], own[pv3(so)], &lkl);
 }
 
 // ---- flip rounds over a work list ---------------------------------------------------
@@ -744,7 +766,8 @@ __global__ __launch_bounds__(256) void k_flip_apply(const int32_t* __restrict__ 
                                                     const unsigned long long* __restrict__ claim,
                                                     int32_t* __restrict__ mark,
                                                     int32_t* __restrict__ next,
-                                                    int32_t* __restrict__ counts /*[0] next size, [1] flips*/) {
+                                                    int32_t* __restrict__ counts /*[0] next size, [1] flips*/,
+                                                    bool push_all) {
   const int m = *m_ptr;
   // wave-uniform trip count: the appends below are wave-cooperative
   for (int base = blockIdx.x * 256; base < m; base += gridDim.x * 256) {
@@ -815,11 +838,23 @@ __global__ __launch_bounds__(256) void k_flip_apply(const int32_t* __restrict__ 
       if (n_bk / 3 != f && n_bk / 3 != g) fn[n_bk] = 3 * g + 0;
       if (n_lb / 3 != f && n_lb / 3 != g) fn[n_lb] = 3 * g + 2;
       flipped = true;
-      // every edge is listed under the smaller of its two half-edge ids
-      push[np++] = min(3 * f + 0, n_al);
-      push[np++] = min(3 * f + 2, n_ka);
-      push[np++] = min(3 * g + 0, n_bk);
-      push[np++] = min(3 * g + 2, n_lb);
+      // The four outer edges go on the next list only if they ARE flip candidates now. The face on the
+      // other side of an outer edge is not rewritten this round (a candidate that owns it yields to us
+      // or we to it, see free_of), so what is seen here is what the next round's k_flip_claim will
+      // see. Listing all four unseen made 60 % of every list edges that the next round looked at and
+      // dropped: 45 M list entries for 9 M flips on a contracted 1 M-point cloud. (Edges glued to the
+      // quad's own faces — copies of the cover folded onto each other — are listed as before.) Every
+      // edge is listed under the smaller of its two half-edge ids.
+      const double own_f[3] = {q.lal, q.lkl, q.lka}, own_g[3] = {q.lbk, q.lkl, q.llb};
+      auto outer = [&](int h_own, const double* own, int h_nbr) {
+        const int fb = h_nbr / 3;
+        if (push_all || fb == f || fb == g || outer_edge_wanted(h_own, own, h_nbr, fl))
+          push[np++] = min(h_own, h_nbr);
+      };
+      outer(3 * f + 0, own_f, n_al);
+      outer(3 * f + 2, own_f, n_ka);
+      outer(3 * g + 0, own_g, n_bk);
+      outer(3 * g + 2, own_g, n_lb);
       // (the flipped edge itself is Delaunay now, by more than the tolerance; it comes back on a
       // list as an outer edge of whichever neighbouring flip next changes one of its faces)
     }
@@ -1292,6 +1327,9 @@ int laplacian_device(Ctx* c, const double* d_xyz, int64_t n, const int64_t* seg_
     PQ_HIP(hipMemcpyAsync(hc, d_cnt, 8, hipMemcpyDeviceToHost, c->stream));
     PQ_HIP(hipStreamSynchronize(c->stream));
     int m = hc[0];  // last list length the host has seen (sizes the next launches)
+    // PYQSM_FLIP_PUSH_ALL=1: a flip lists its four outer edges unseen (the earlier form; same flips, same result)
+    const char* e_push = getenv("PYQSM_FLIP_PUSH_ALL");
+    const bool push_all = e_push && e_push[0] == '1';
     int last_flips = -1, same_looks = 0;
     for (int round = 0; round < kMaxFlipRounds && m > 0;) {
       // a batch of rounds between two looks at the counters; the lists shrink fast, and a
@@ -1305,7 +1343,7 @@ int laplacian_device(Ctx* c, const double* d_xyz, int64_t n, const int64_t* seg_
         hipLaunchKernelGGL(k_flip_claim, gm, blk, 0, c->stream, d_cnt + 2 * round, cur, stamp, d_fl,
                            d_fn, d_claim, d_iscand);
         hipLaunchKernelGGL(k_flip_apply, gm, blk, 0, c->stream, d_cnt + 2 * round, cur, d_iscand, stamp,
-                           round, d_fv, d_fl, d_fn, d_claim, d_mark, nxt, d_cnt + 2 * (round + 1));
+                           round, d_fv, d_fl, d_fn, d_claim, d_mark, nxt, d_cnt + 2 * (round + 1), push_all);
       }
       PQ_HIP(hipGetLastError());
       PQ_HIP(hipMemcpyAsync(hc, d_cnt + 2 * round, 8, hipMemcpyDeviceToHost, c->stream));
@@ -1325,6 +1363,15 @@ int laplacian_device(Ctx* c, const double* d_xyz, int64_t n, const int64_t* seg_
       last_flips = hc[1];
       m = hc[0];
       if (getenv("PYQSM_LBC_TRACE")) fprintf(stderr, "flip round %d list %d flips(last) %d\n", round, hc[0], hc[1]);
+    }
+    if (getenv("PYQSM_LBC_TRACE")) {  // the rounds' own counters: list length going in, flips made
+      std::vector<int32_t> hcnt(size_t(kMaxFlipRounds + 2) * 2);
+      PQ_HIP(hipMemcpyAsync(hcnt.data(), d_cnt, hcnt.size() * 4, hipMemcpyDeviceToHost, c->stream));
+      PQ_HIP(hipStreamSynchronize(c->stream));
+      fprintf(stderr, "flip rounds of a cover of %d faces (list, flips):", F);
+      for (int r = 0; r < kMaxFlipRounds && hcnt[2 * size_t(r)] > 0; ++r)
+        fprintf(stderr, " %d:%d", hcnt[2 * size_t(r)], hcnt[2 * size_t(r) + 3]);
+      fprintf(stderr, "\n");
     }
     if (getenv("PYQSM_LBC_TRACE")) {  // the rounds' own counters: list length going in, flips made
       std::vector<int32_t> hcnt(size_t(kMaxFlipRounds + 2) * 2);

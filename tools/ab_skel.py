@@ -17,6 +17,9 @@ for rep in range(2):
     got, total, steps = sk.extract_skeleton(P, max_iter=20, termination_ratio=0.0, contraction_factor=c)
     dt = time.perf_counter() - t
     it = hip.prof_get("lbc_amg_iter")
+    lap = sum(hip.prof_get(k)[0] for k in ("lap_knn", "lap_fans", "lap_assemble"))
+    flips = hip.prof_get("lap_flips")[0]
     hip.prof_enable(False)
     print(f"n={n} c={c}: {dt:.3f} s, multigrid-CG iterations {it[1]} in {it[0]:.0f} ms ({it[0]/max(it[1],1)*1e3:.1f} us each), "
-          f"sha {hashlib.sha1(total.tobytes()).hexdigest()[:12]} env FUSED_TAIL={os.environ.get('PYQSM_AMG_FUSED_TAIL','1')}", flush=True)
+          f"Laplacian builds {lap:.0f} ms (flips {flips:.0f}), sha {hashlib.sha1(total.tobytes()).hexdigest()[:12]} env "
+          + " ".join(f"{k[6:]}={v}" for k, v in os.environ.items() if k.startswith("PYQSM_")), flush=True)
