@@ -21,7 +21,7 @@
 //   smoother      l1-Jacobi (x += (b - Bx)_i / sum_j |B_ij|), one sweep before and
 //                 one after the coarse correction, fused with the residual and the
 //                 prolongation: three launches per level and cycle
-//   coarsest      <= kCoarseMax unknowns: dense inverse computed on the host once
+//   coarsest      <= kDenseMax unknowns: dense inverse, made once per hierarchy (k_gj_*; host Cholesky <= kCoarseMax)
 //
 // (Measured: running the levels below 4096 unknowns inside ONE workgroup with barriers, to
 // save their three launches each, was 10-15 % slower at 50 k-1 M points than the launches:
@@ -39,7 +39,9 @@
 
 namespace pyqsm {
 
-static constexpr int kCoarseMax = 96;   // dense solve at or below this size
+static constexpr int kCoarseMax = 96;   // dense solve by one workgroup (inverse from the host) at or below this size
+static constexpr int kDenseMax = 1024;  // dense inverse made on the device at or below this size (dense_max())
+static constexpr int kGjBlock = 32;     // pivot block of the device inverse
 static constexpr int kRowCap = 64;      // distinct coarse neighbours one coarse row may have
 static constexpr int kMaxLevels = 24;
 static constexpr double kTheta = 0.08;  // strength-of-connection threshold
@@ -79,8 +81,10 @@ struct AmgLevel {
 
 struct AmgHierarchy {
   std::vector<AmgLevel> lv;
-  double* dense_inv = nullptr;  // [nc, nc] on the device, transposed
+  double* dense_inv = nullptr;  // [nc, nc] on the device, transposed (host Cholesky, nc <= kCoarseMax)
   int nc = 0;
+  double* dense_gj = nullptr;   // [ld, ld] row-major inverse made on the device (k_gj_*), nc <= dense_max()
+  int ld = 0;                   // nc rounded up to kGjBlock
 };
 
 // ---- level construction kernels ------------------------------------------------
@@ -796,6 +800,128 @@ __global__ __launch_bounds__(3 * kCoarseMax) void k_dense_solve(int nc, const do
   dense_solve_block(nc, ainv_t, b, x);
 }
 
+// ---- dense inverse on the device (round 3) ---------------------------------------------------
+// A hierarchy used to go down to <= 96 unknowns, where a host-made Cholesky inverse finishes the
+// cycle. The small levels cost what a large one costs — three launches, each a chain of dependent
+// memory trips, ~4.7 us — so the levels of ~1 000, ~260 and ~90 rows were 9 of the ~24 launches of
+// a cycle and a quarter of its time. Now the coarsening stops at <= kDenseMax rows and that level is
+// solved exactly by ONE matrix-vector product with its inverse, which is made here once per
+// hierarchy: block Gauss-Jordan in place without pivoting (the matrix is symmetric positive
+// definite: W_H > 0 on the diagonal of an M-matrix), 32 columns at a time, three launches a block.
+//   P = A[K,K]^-1 ;  U = P A[K,R] ;  C = A[R,K] ;  A[R,R] -= C U ;  A[K,R] = U ;  A[R,K] = -C P ;  A[K,K] = P
+// The matrix is padded with an identity to a multiple of 32 rows (ld), so every block is full.
+
+__global__ __launch_bounds__(256) void k_dense_from_csr(int n, int ld, const int32_t* __restrict__ indptr,
+                                                        const int32_t* __restrict__ indices,
+                                                        const double* __restrict__ vals,
+                                                        double* __restrict__ A /* zeroed */) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= ld) return;
+  if (i >= n) {
+    A[size_t(i) * ld + i] = 1.0;
+    return;
+  }
+  for (int j = indptr[i]; j < indptr[i + 1]; ++j) A[size_t(i) * ld + indices[j]] += vals[j];
+}
+
+// P = A[K,K]^-1 by Gauss-Jordan in LDS, one thread per element; flag[0] = 1 on a pivot that is not positive
+__global__ __launch_bounds__(kGjBlock * kGjBlock) void k_gj_pivot(int ld, int k0, const double* __restrict__ A,
+                                                                  double* __restrict__ P, int32_t* __restrict__ flag) {
+  __shared__ double M[kGjBlock][kGjBlock + 1];
+  const int r = threadIdx.x / kGjBlock, cc = threadIdx.x % kGjBlock;
+  M[r][cc] = A[size_t(k0 + r) * ld + k0 + cc];
+  __syncthreads();
+  for (int p = 0; p < kGjBlock; ++p) {
+    const double piv = M[p][p], f = M[r][p], pc = M[p][cc];
+    __syncthreads();
+    if (!(piv > 0.0) && threadIdx.x == 0) flag[0] = 1;
+    const double inv = 1.0 / piv;
+    if (r == p)
+      M[r][cc] = cc == p ? inv : pc * inv;
+    else
+      M[r][cc] = cc == p ? -(f * inv) : M[r][cc] - f * (pc * inv);
+    __syncthreads();
+  }
+  P[r * kGjBlock + cc] = M[r][cc];
+}
+
+// U[t][j] = sum_s P[t][s] A[k0+s][j]  and  C[i][t] = A[i][k0+t]  (thread = column j = row i)
+__global__ __launch_bounds__(256) void k_gj_panels(int ld, int k0, const double* __restrict__ A,
+                                                   const double* __restrict__ P, double* __restrict__ U,
+                                                   double* __restrict__ C) {
+  __shared__ double sp[kGjBlock * kGjBlock];
+  for (int t = threadIdx.x; t < kGjBlock * kGjBlock; t += 256) sp[t] = P[t];
+  __syncthreads();
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= ld) return;
+  double a[kGjBlock];
+#pragma unroll
+  for (int sidx = 0; sidx < kGjBlock; ++sidx) a[sidx] = A[size_t(k0 + sidx) * ld + j];
+  for (int t = 0; t < kGjBlock; ++t) {
+    double acc = 0.0;
+#pragma unroll
+    for (int sidx = 0; sidx < kGjBlock; ++sidx) acc += sp[t * kGjBlock + sidx] * a[sidx];
+    U[size_t(t) * ld + j] = acc;
+  }
+#pragma unroll
+  for (int t = 0; t < kGjBlock; ++t) C[size_t(j) * kGjBlock + t] = A[size_t(j) * ld + k0 + t];
+}
+
+// the update of one 32 x 32 tile (256 threads, four elements each)
+__global__ __launch_bounds__(256) void k_gj_update(int ld, int k0, double* __restrict__ A,
+                                                   const double* __restrict__ P, const double* __restrict__ U,
+                                                   const double* __restrict__ C) {
+  __shared__ double sc[kGjBlock][kGjBlock + 1];  // C rows of the tile, or P
+  __shared__ double su[kGjBlock][kGjBlock + 1];  // U columns of the tile, or P
+  const int i0 = blockIdx.y * kGjBlock, j0 = blockIdx.x * kGjBlock;
+  const bool row_k = i0 == k0, col_k = j0 == k0;
+  for (int t = threadIdx.x; t < kGjBlock * kGjBlock; t += 256) {
+    const int r = t / kGjBlock, q = t % kGjBlock;
+    sc[r][q] = row_k ? 0.0 : C[size_t(i0 + r) * kGjBlock + q];                     // C[i][t]
+    su[r][q] = col_k ? P[r * kGjBlock + q] : U[size_t(r) * ld + j0 + q];           // U[t][j] or P[t][j]
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < kGjBlock * kGjBlock; t += 256) {
+    const int r = t / kGjBlock, q = t % kGjBlock;
+    double* out = A + size_t(i0 + r) * ld + j0 + q;
+    if (row_k) {
+      *out = su[r][q];  // U[i - k0][j], or P[i - k0][j - k0] in the pivot tile
+    } else {
+      double acc = 0.0;
+#pragma unroll
+      for (int m = 0; m < kGjBlock; ++m) acc += sc[r][m] * su[m][q];
+      *out = col_k ? -acc : *out - acc;
+    }
+  }
+}
+
+// x = Ainv b on the coarsest level, a wave per row (b staged in LDS, fp64 accumulation, the lanes'
+// partial sums folded in a fixed butterfly)
+__global__ __launch_bounds__(256) void k_dense_mv(int n, int ld, const double* __restrict__ ainv,
+                                                  const float* __restrict__ b, float* __restrict__ x) {
+  __shared__ float4 sb[kDenseMax];
+  for (int j = threadIdx.x; j < n; j += 256) sb[j] = ld4(b, j);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;  // whole waves
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  const double* row = ainv + size_t(i) * ld;
+  for (int j = lane; j < n; j += 64) {
+    const double a = row[j];
+    const float4 v = sb[j];
+    s0 += a * double(v.x);
+    s1 += a * double(v.y);
+    s2 += a * double(v.z);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    s0 += __shfl_xor(s0, off, 64);
+    s1 += __shfl_xor(s1, off, 64);
+    s2 += __shfl_xor(s2, off, 64);
+  }
+  if (lane == 0) st4(x, i, float(s0), float(s1), float(s2));
+}
+
 // (Round 2 experiment, dropped: the levels of <= 4096 / 2048 / 1024 / 512 rows down to the dense
 // solve run by ONE 1024-thread workgroup, level after level with workgroup barriers instead of a
 // launch per level and pass — same row functions, bit-identical results, and no faster: 1933-1972
@@ -876,6 +1002,43 @@ static int coarse_inverse(Ctx* c, const AmgLevel& L, double** d_inv) {
   PQ_TRY(c->arena.get(size_t(n) * n, d_inv));
   PQ_HIP(hipMemcpyAsync(*d_inv, A.data(), size_t(n) * n * 8, hipMemcpyHostToDevice, c->stream));
   PQ_HIP(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+static int dense_max() {  // PYQSM_AMG_DENSE_MAX: rows of the level that is solved by a dense inverse (<= kDenseMax)
+  static const int v = [] {
+    const char* e = getenv("PYQSM_AMG_DENSE_MAX");
+    const int q = e ? atoi(e) : kDenseMax;
+    return std::max(kCoarseMax, std::min(q, kDenseMax));
+  }();
+  return v;
+}
+
+// Dense inverse of the coarsest matrix on the device (kCoarseMax < n <= kDenseMax): see k_gj_*.
+static int coarse_inverse_device(Ctx* c, const AmgLevel& L, double** d_inv, int* ld_out, int32_t* d_flag) {
+  const int n = L.n, ld = ceil_div(n, kGjBlock) * kGjBlock;
+  double *A, *P, *U, *C;
+  PQ_TRY(c->arena.get(size_t(ld) * ld, &A));
+  PQ_TRY(c->arena.get(size_t(kGjBlock) * kGjBlock, &P));
+  PQ_TRY(c->arena.get(size_t(kGjBlock) * ld, &U));
+  PQ_TRY(c->arena.get(size_t(ld) * kGjBlock, &C));
+  PQ_HIP(hipMemsetAsync(A, 0, size_t(ld) * ld * 8, c->stream));
+  PQ_HIP(hipMemsetAsync(d_flag, 0, 4, c->stream));
+  hipLaunchKernelGGL(k_dense_from_csr, dim3(ceil_div(ld, 256)), dim3(256), 0, c->stream, n, ld, L.A.indptr,
+                     L.A.indices, L.A.vals, A);
+  const dim3 tiles(ld / kGjBlock, ld / kGjBlock);
+  for (int k0 = 0; k0 < ld; k0 += kGjBlock) {
+    hipLaunchKernelGGL(k_gj_pivot, dim3(1), dim3(kGjBlock * kGjBlock), 0, c->stream, ld, k0, A, P, d_flag);
+    hipLaunchKernelGGL(k_gj_panels, dim3(ceil_div(ld, 256)), dim3(256), 0, c->stream, ld, k0, A, P, U, C);
+    hipLaunchKernelGGL(k_gj_update, tiles, dim3(256), 0, c->stream, ld, k0, A, P, U, C);
+  }
+  PQ_HIP(hipGetLastError());
+  int32_t bad = 0;
+  PQ_HIP(hipMemcpyAsync(&bad, d_flag, 4, hipMemcpyDeviceToHost, c->stream));
+  PQ_HIP(hipStreamSynchronize(c->stream));
+  if (bad) return fail(PYQSM_EINVAL, "multigrid: coarsest matrix is not positive definite");
+  *d_inv = A;
+  *ld_out = ld;
   return 0;
 }
 
@@ -995,7 +1158,7 @@ int amg_build(Ctx* c, const DevCsr& Lm, int n, const double* cw, const double* w
   AMG_TRY(c->arena.get(2, &d_flag));
   for (int lev = 0; lev < kMaxLevels; ++lev) {
     AmgLevel& F = H->lv.back();
-    if (F.n <= kCoarseMax) break;
+    if (F.n <= dense_max()) break;
     int nc = 0;
     AMG_TRY(aggregate(c, F, d_flag, &nc));
     if (nc <= 0 || nc > 0.8 * F.n) {  // nothing (left) to coarsen
@@ -1064,6 +1227,9 @@ int amg_build(Ctx* c, const DevCsr& Lm, int n, const double* cw, const double* w
   if (last.n <= kCoarseMax && H->lv.size() > 1) {
     H->nc = last.n;
     AMG_TRY(coarse_inverse(c, last, &H->dense_inv));
+  } else if (last.n <= dense_max() && H->lv.size() > 1) {
+    H->nc = last.n;
+    AMG_TRY(coarse_inverse_device(c, last, &H->dense_gj, &H->ld, d_flag));
   }
   if (getenv("PYQSM_LBC_TRACE")) {
     fprintf(stderr, "multigrid levels:");
@@ -1120,6 +1286,8 @@ static int vcycle_impl(Ctx* c, AmgHierarchy* H, const TV* b, TV* x, double* dot)
     if (l == nl - 1) {  // (never level 0: hierarchies with a single level are not used)
       if (H->dense_inv) {
         hipLaunchKernelGGL(k_dense_solve, dim3(1), dim3(3 * kCoarseMax), 0, c->stream, L.n, H->dense_inv, bl, L.xb);
+      } else if (H->dense_gj) {
+        hipLaunchKernelGGL(k_dense_mv, dim3(ceil_div(L.n, 4)), blk, 0, c->stream, L.n, H->ld, H->dense_gj, bl, L.xb);
       } else if (L.n <= kFusedTailMaxRows && fused_tail_enabled()) {  // the same sweeps in one launch
         PQ_TRY(allow_fused_tail_lds(c));
         hipLaunchKernelGGL(k_tail_sweeps, dim3(1), dim3(kFusedTailThreads), size_t(L.n) * kVecStride * 4 * 3, c->stream,
