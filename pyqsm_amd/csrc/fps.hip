@@ -375,14 +375,15 @@ __global__ __launch_bounds__(256) void k_fps_pruned(int s, int start_idx, int nb
 // nothing that could wait for another block — on a hierarchy that is compact against the reach:
 //   the points in Morton order of a 1024^3 grid over the cloud's box, 64 consecutive points = a BUCKET
 //   (bounding box + farthest point, in memory as separate arrays: a wave's gather is eleven contiguous
-//   loads), 16 consecutive buckets = a GROUP and 64 groups = a SUPER, both with box and farthest point in
-//   LDS. A round: supers whose groups changed fold their group maxima again -> the best super maximum is
-//   the sample (its coordinates travel with the record: no look-up) -> supers, then groups whose box is
-//   closer than their largest distance (LDS) -> their buckets' records and boxes, ONE gather, kept in
-//   LDS -> the buckets the sample can improve are updated, a wave each and a point per lane, the loads
-//   of four buckets in flight together; a bucket's farthest point changes only if that very point moved
-//   closer, otherwise its record stands and no reduction runs -> the groups that changed fold their
-//   sixteen records from LDS. Two dependent memory round trips per round and five barriers of four waves.
+//   loads), 16 consecutive buckets = a GROUP with box and farthest point in LDS; every thread OWNS up to
+//   five groups and keeps their boxes in registers. A round: every thread the best of its groups, a DPP
+//   fold per wave, the four winners (with their coordinates: no look-up) through LDS -> the sample ->
+//   groups whose box is closer than their largest distance (registers) -> their buckets' records and
+//   boxes, ONE gather, kept in LDS -> the buckets the sample can improve are updated, a wave each and a
+//   point per lane, the loads of four buckets in flight together; a bucket's farthest point changes only
+//   if that very point moved closer, otherwise its record stands and no reduction runs -> the groups that
+//   changed fold their sixteen records from LDS. Two dependent memory round trips per round and five
+//   barriers of four waves.
 // Every box test is exact for the same reason the bucket test of k_fps_pruned is: a parent's box contains
 // its children's boxes and its maximum bounds theirs, and every term is rounded monotonically, so a parent
 // that fails the test holds no child that would pass. Same distances, same comparison, same indices as
@@ -394,15 +395,18 @@ __global__ __launch_bounds__(256) void k_fps_pruned(int s, int start_idx, int nb
 // and 130 KB of points per round); Morton-ordered 64-point buckets, four waves: 8.2 us (array-of-struct
 // records: 250 cache-line requests per gather, buckets updated one after the other); records as separate
 // arrays, 16-bucket groups, four buckets' loads in flight: 6.2 us; supers, dirty tracking and the skipped
-// reductions: 5.3 us.
+// reductions: 5.3 us; the supers dropped again for the flat scan with register-resident group boxes: 4.7 us
+// (argmax 1.0, group test 0.85, bucket gather 0.85, update 1.5, fold 0.45: the first two and the last
+// touch no memory at all — with ONE wave per SIMD every dependent instruction costs its full latency,
+// ~250 instructions of compare / DPP / select are a microsecond; the other two are one memory trip each).
 static constexpr int kTailThreads = 256;     // four waves: barriers and reductions are the fixed cost of a round
 static constexpr int kTailWaves = kTailThreads / 64;
 static constexpr int kTailBucket = 64;       // points per bucket in the tail: a lane each
 static constexpr int kTailGroup = 16;        // buckets per group: a wave takes four groups at a time
 static constexpr int kTailPerWave = 64 / kTailGroup;
 static constexpr int kTailMaxGroups = 1280;  // LDS: 88 bytes per group (1.3 M points; larger clouds keep the launches)
+static constexpr int kTailOwn = kTailMaxGroups / 256;  // groups a thread owns (their boxes live in its registers)
 static constexpr int kTailUnroll = 4;        // buckets a wave updates with their loads issued side by side
-static constexpr int kTailMaxSupers = (kTailMaxGroups + 63) / 64;
 
 struct TailRec {  // a bucket's (or a group's) farthest point, with its coordinates
   double d;
@@ -610,19 +614,25 @@ __global__ __launch_bounds__(kTailThreads) void k_fps_tail(
     unsigned long long* __restrict__ dbg /*diagnostic: phase clocks (100 MHz ticks) and counts, may be null*/) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  TailRec* gmax = reinterpret_cast<TailRec*>(smem);                                // [ng]
-  double* gbox = reinterpret_cast<double*>(smem + size_t(ng) * sizeof(TailRec));   // [ng][6]
+  // the groups' farthest points and boxes as separate arrays [ng] (a thread reads the same field of
+  // consecutive groups: no bank conflicts), 88 bytes per group
+  double* g_d = reinterpret_cast<double*>(smem);
+  double* g_x = g_d + ng;
+  double* g_y = g_x + ng;
+  double* g_z = g_y + ng;
+  double* g_box = g_z + ng;  // [6][ng]
+  int* g_idx = reinterpret_cast<int*>(g_box + 6 * size_t(ng));
+  int* g_pos = g_idx + ng;
   __shared__ TailRec grec[kTailWaves][64];  // the records of the groups of the current batch (four per wave)
-  __shared__ TailRec smax[kTailMaxSupers];  // a SUPER = 64 consecutive groups: its farthest point ...
-  __shared__ double sbox[kTailMaxSupers][6];  // ... and box (boxes never change)
-  __shared__ int sdirty[kTailMaxSupers];      // a group of the super changed: its maximum is folded again
+  __shared__ double wb_d[kTailWaves];       // every wave's best group of the round
+  __shared__ double wb_x[kTailWaves], wb_y[kTailWaves], wb_z[kTailWaves];
+  __shared__ int wb_idx[kTailWaves];
   __shared__ int gdirty[kTailWaves * kTailPerWave];
   __shared__ int glist[kTailMaxGroups];
   __shared__ int2 blist[kTailWaves * 64];  // (bucket, slot in grec)
   __shared__ int n_g, n_b;
   const int tid_ = threadIdx.x, lane = tid_ & 63, wave = tid_ >> 6;
   const int sub = lane / kTailGroup, gl = lane % kTailGroup;  // group slot of the wave, bucket in the group
-  const int ns = (ng + 63) / 64;
   const TailRec none{-1.0, 0x7FFFFFFF, 0, 0.0, 0.0, 0.0};
   auto axis = [](double p, double lo, double hi) { return p < lo ? lo - p : (p > hi ? p - hi : 0.0); };
   auto box_d2 = [&](double px, double py, double pz, const double* bx) {
@@ -630,6 +640,14 @@ __global__ __launch_bounds__(kTailThreads) void k_fps_tail(
     double m2 = t0 * t0;
     m2 = m2 + t1 * t1;
     return m2 + t2 * t2;
+  };
+  auto put_group = [&](int g, const TailRec& m) {
+    g_d[g] = m.d;
+    g_idx[g] = m.idx;
+    g_pos[g] = m.pos;
+    g_x[g] = m.x;
+    g_y[g] = m.y;
+    g_z[g] = m.z;
   };
   // group records from the bucket records
   for (int g0 = wave * kTailPerWave; g0 < ng; g0 += kTailWaves * kTailPerWave) {
@@ -655,71 +673,102 @@ __global__ __launch_bounds__(kTailThreads) void k_fps_tail(
         hi[a] = fmax(hi[a], __shfl_xor(hi[a], off, 64));
       }
     if (gl == 0 && g < ng) {
-      gmax[g] = m;
+      put_group(g, m);
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
-        gbox[6 * g + a] = lo[a];
-        gbox[6 * g + 3 + a] = hi[a];
+        g_box[size_t(a) * ng + g] = lo[a];
+        g_box[size_t(3 + a) * ng + g] = hi[a];
       }
     }
   }
   __syncthreads();
-  // super boxes; every super starts dirty
-  for (int sp = wave; sp < ns; sp += kTailWaves) {
-    const int g = sp * 64 + lane;
-    double lo[3] = {__builtin_inf(), __builtin_inf(), __builtin_inf()};
-    double hi[3] = {-__builtin_inf(), -__builtin_inf(), -__builtin_inf()};
-    if (g < ng) {
+  // a thread OWNS the groups tid, tid + 256, ...: their boxes (which never change) stay in its registers
+  double own_box[kTailOwn][6];
 #pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        lo[a] = gbox[6 * g + a];
-        hi[a] = gbox[6 * g + 3 + a];
-      }
-    }
+  for (int k = 0; k < kTailOwn; ++k) {
+    const int g = tid_ + k * kTailThreads;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        lo[a] = fmin(lo[a], __shfl_xor(lo[a], off, 64));
-        hi[a] = fmax(hi[a], __shfl_xor(hi[a], off, 64));
-      }
-    if (lane == 0) {
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        sbox[sp][a] = lo[a];
-        sbox[sp][3 + a] = hi[a];
-      }
-      sdirty[sp] = 1;
-    }
+    for (int a = 0; a < 6; ++a) own_box[k][a] = g < ng ? g_box[size_t(a) * ng + g] : 0.0;
   }
-  __syncthreads();
   const unsigned long long clk0 = dbg ? clock64() : 0;
   for (int s = s_begin; s < s_end; ++s) {
     unsigned long long t0 = dbg ? wall_clock64() : 0;
-    // 1. the farthest point of all: supers whose groups changed fold their 64 group maxima again, then
-    //    every wave takes the best of the (at most 20) super maxima itself
-    for (int sp = wave; sp < ns; sp += kTailWaves) {
-      if (!sdirty[sp]) continue;  // wave-uniform
-      const int g = sp * 64 + lane;
-      const TailRec m = tail_best(g < ng ? gmax[g] : none);
-      if (lane == 0) {
-        smax[sp] = m;
-        sdirty[sp] = 0;
+    // 1. the farthest point of all: every thread the best of the groups it owns (their records read side
+    //    by side, then compared in registers), a DPP fold per wave, the four waves' winners — with their
+    //    coordinates — through LDS. (A level of 64-group "supers" with dirty flags above the groups made
+    //    this 1.2 us of a round and the group test below another 1.2: a wave per super, 40-byte records
+    //    out of LDS, two folds one after the other.)
+    double od[kTailOwn];
+    {
+      int oi[kTailOwn];
+#pragma unroll
+      for (int k = 0; k < kTailOwn; ++k) {
+        const int g = tid_ + k * kTailThreads;
+        od[k] = g < ng ? g_d[g] : -1.0;
+        oi[k] = g < ng ? g_idx[g] : 0x7FFFFFFF;
       }
+      double bd = od[0];
+      int bi = oi[0], bk = 0;
+#pragma unroll
+      for (int k = 1; k < kTailOwn; ++k)
+        if (od[k] > bd || (od[k] == bd && oi[k] < bi)) {
+          bd = od[k];
+          bi = oi[k];
+          bk = k;
+        }
+      const unsigned long long kd = ord_bits(bd);
+      const unsigned long long topk = wave_max_u64(kd);
+      unsigned long long who = __ballot(kd == topk);
+      if (who & (who - 1)) {  // several lanes at the maximum (wave-uniform): the lowest index among them
+        const unsigned ki = kd == topk ? 0x7FFFFFFFu - unsigned(bi) : 0u;
+        const unsigned ti = wave_max_u32(ki);
+        who = __ballot(kd == topk && ki == ti);
+      }
+      const int src = __builtin_amdgcn_readfirstlane(__ffsll(who) - 1);
+      if (lane == src) {
+        const int bg = min(tid_ + bk * kTailThreads, ng - 1);
+        wb_d[wave] = bd;
+        wb_idx[wave] = bi;
+        wb_x[wave] = g_x[bg];
+        wb_y[wave] = g_y[bg];
+        wb_z[wave] = g_z[bg];
+      }
+      if (tid_ == 0) n_g = 0;
     }
-    if (tid_ == 0) n_g = 0;
     __syncthreads();
-    const TailRec top = tail_best(lane < ns ? smax[lane] : none);
-    if (tid_ == 0) out[s] = top.idx;
-    const double px = top.x, py = top.y, pz = top.z;
+    double px, py, pz;
+    {
+      double wd[kTailWaves], wx[kTailWaves], wy[kTailWaves], wz[kTailWaves];
+      int wi[kTailWaves];
+#pragma unroll
+      for (int w = 0; w < kTailWaves; ++w) {
+        wd[w] = wb_d[w];
+        wi[w] = wb_idx[w];
+        wx[w] = wb_x[w];
+        wy[w] = wb_y[w];
+        wz[w] = wb_z[w];
+      }
+      double bd = wd[0];
+      int bi = wi[0];
+      px = wx[0], py = wy[0], pz = wz[0];
+#pragma unroll
+      for (int w = 1; w < kTailWaves; ++w)
+        if (wd[w] > bd || (wd[w] == bd && wi[w] < bi)) {
+          bd = wd[w];
+          bi = wi[w];
+          px = wx[w], py = wy[w], pz = wz[w];
+        }
+      if (tid_ == 0) out[s] = bi;
+    }
     if (dbg) { const unsigned long long t = wall_clock64(); acc[0] += t - t0; t0 = t; }
-    // 2. groups the sample can still improve: the supers first, then the groups of the supers in reach
-    for (int sp = wave; sp < ns; sp += kTailWaves) {
-      if (!(box_d2(px, py, pz, sbox[sp]) < smax[sp].d)) continue;  // wave-uniform
-      const int g = sp * 64 + lane;
-      const bool hit = g < ng && box_d2(px, py, pz, gbox + 6 * g) < gmax[g].d;
+    // 2. groups the sample can still improve: box closer than the group's largest distance — all in
+    //    registers (own_box, od)
+#pragma unroll
+    for (int k = 0; k < kTailOwn; ++k) {
+      const int g = tid_ + k * kTailThreads;
+      const bool hit = g < ng && box_d2(px, py, pz, own_box[k]) < od[k];
       const unsigned long long mask = __ballot(hit);
-      if (mask) {
+      if (mask) {  // wave-uniform
         int base = 0;
         if (lane == 0) base = atomicAdd(&n_g, __popcll(mask));
         base = __shfl(base, 0, 64);
@@ -812,10 +861,7 @@ __global__ __launch_bounds__(kTailThreads) void k_fps_tail(
                   d2 = gdirty[wave * kTailPerWave + 2], d3 = gdirty[wave * kTailPerWave + 3];
         if (d0 | d1 | d2 | d3) {  // wave-uniform
           const TailRec m = row_best(grec[wave][lane]);
-          if (gl == 0 && q < ngl && gdirty[wave * kTailPerWave + sub]) {
-            gmax[glist[q]] = m;
-            sdirty[glist[q] >> 6] = 1;
-          }
+          if (gl == 0 && q < ngl && gdirty[wave * kTailPerWave + sub]) put_group(glist[q], m);
         }
       }
       __syncthreads();
