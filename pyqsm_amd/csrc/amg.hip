@@ -1006,12 +1006,9 @@ static int coarse_inverse(Ctx* c, const AmgLevel& L, double** d_inv) {
 }
 
 static int dense_max() {  // PYQSM_AMG_DENSE_MAX: rows of the level that is solved by a dense inverse (<= kDenseMax)
-  static const int v = [] {
-    const char* e = getenv("PYQSM_AMG_DENSE_MAX");
-    const int q = e ? atoi(e) : kDenseMax;
-    return std::max(kCoarseMax, std::min(q, kDenseMax));
-  }();
-  return v;
+  const char* e = getenv("PYQSM_AMG_DENSE_MAX");
+  const int q = e ? atoi(e) : kDenseMax;
+  return std::max(kCoarseMax, std::min(q, kDenseMax));
 }
 
 // Dense inverse of the coarsest matrix on the device (kCoarseMax < n <= kDenseMax): see k_gj_*.
@@ -1156,9 +1153,10 @@ int amg_build(Ctx* c, const DevCsr& Lm, int n, const double* cw, const double* w
   // ---- coarsen -------------------------------------------------------------------------
   int32_t* d_flag = nullptr;
   AMG_TRY(c->arena.get(2, &d_flag));
+  const int dmax = dense_max();
   for (int lev = 0; lev < kMaxLevels; ++lev) {
     AmgLevel& F = H->lv.back();
-    if (F.n <= dense_max()) break;
+    if (F.n <= dmax) break;
     int nc = 0;
     AMG_TRY(aggregate(c, F, d_flag, &nc));
     if (nc <= 0 || nc > 0.8 * F.n) {  // nothing (left) to coarsen
@@ -1227,7 +1225,7 @@ int amg_build(Ctx* c, const DevCsr& Lm, int n, const double* cw, const double* w
   if (last.n <= kCoarseMax && H->lv.size() > 1) {
     H->nc = last.n;
     AMG_TRY(coarse_inverse(c, last, &H->dense_inv));
-  } else if (last.n <= dense_max() && H->lv.size() > 1) {
+  } else if (last.n <= dmax && H->lv.size() > 1) {
     H->nc = last.n;
     AMG_TRY(coarse_inverse_device(c, last, &H->dense_gj, &H->ld, d_flag));
   }

@@ -171,6 +171,36 @@ def test_riccati_weighted_preconditioner_same_solution_fewer_iterations(gpu, mon
     assert it1 < it0
 
 
+def test_dense_coarsest_level_made_on_the_device(gpu, monkeypatch, capfd):
+    """The multigrid stops coarsening at <= 1024 rows and solves that level with a dense inverse made on
+    the device (amg.hip: k_gj_pivot / panels / update, k_dense_mv); PYQSM_AMG_DENSE_MAX=96 is the
+    earlier hierarchy (down to <= 96 rows, inverse by host Cholesky). Same system, both ways: the
+    hierarchies differ as stated, both solves converge, the solutions agree to the solver's tolerance
+    and the iteration counts stay close (the coarse solve is exact either way)."""
+    from pyqsm_amd import synth
+    from pyqsm_amd.geometry import skeletonize as sk
+    P = synth.forest(60_000, seed=6)
+    L, M = sk.point_cloud_laplacian(P, mollify_factor=1e-6, n_neighbors=20, device=gpu)
+    wl = np.full(len(P), 3 * 1e3 * np.sqrt(np.mean(M.diagonal())))
+    wh = np.full(len(P), 3.0)
+    monkeypatch.setenv("PYQSM_LBC_TRACE", "1")
+    out, last = {}, {}
+    for dmax in ("96", "1024"):
+        monkeypatch.setenv("PYQSM_AMG_DENSE_MAX", dmax)
+        capfd.readouterr()
+        out[dmax] = hip.lbc_solve(L, wl, wh, P, rtol=1e-8, device=gpu)
+        levels = [ln for ln in capfd.readouterr().err.splitlines() if ln.startswith("multigrid levels:")]
+        last[dmax] = int(levels[0].split()[-1])
+    assert last["96"] <= 96 < last["1024"] <= 1024
+    (x0, it0, _, ok0), (x1, it1, _, ok1) = out["96"], out["1024"]
+    assert ok0 and ok1
+    scale = np.abs(x0).max()
+    print(f"coarsest {last['96']} rows: {it0} iterations; coarsest {last['1024']} rows: {it1}; "
+          f"difference {np.abs(x0 - x1).max() / scale:.1e}")
+    assert np.abs(x0 - x1).max() <= 1e-6 * scale
+    assert abs(it1 - it0) <= 0.15 * it0
+
+
 def test_diverging_fp32_inner_solve_falls_back_to_the_fp64_operator(gpu, monkeypatch, capfd):
     """On a collapsed cloud with a very large W_L the fp32 multigrid-CG solves of the
     preconditioner B^-1 B^-1 diverge (c L_ii ~ 1e9 next to W_H = 0.1 is beyond what fp32 rows

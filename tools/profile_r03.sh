@@ -11,7 +11,9 @@ O=/tmp/prof_r03
 rm -rf $O; mkdir -p $O
 DB="--steps 5 --warmup 1 --no-rays --no-knn --no-skeleton --no-ransac --no-cpu"
 KN="--steps 2 --warmup 1 --no-rays --no-skeleton --no-ransac --no-cpu"
-run() { name=$1; shift; timeout -k 10 500 rocprofv3 "$@" > $O/$name.json 2> $O/$name.err; echo "$name rc=$?" >> $O/steps.log; }
+# a pass that runs into its limit ends the script: no further GPU step after a kill
+run() { name=$1; shift; timeout -k 10 500 rocprofv3 "$@" > $O/$name.json 2> $O/$name.err; rc=$?; echo "$name rc=$rc" >> $O/steps.log;
+        if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then mkdir -p $R/gpurun_out/prof_r03_summary; cp $O/steps.log $R/gpurun_out/prof_r03_summary/; echo "$name timed out: stopping"; exit 1; fi; }
 run bench      --kernel-trace --stats --output-format csv -d $O/bench -o bench -- python3 $R/bench.py --no-cpu --no-config5
 run fetch      --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -o f -- python3 $R/bench.py $DB
 run write      --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -o w -- python3 $R/bench.py $DB
