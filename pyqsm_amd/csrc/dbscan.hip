@@ -75,6 +75,8 @@ __global__ __launch_bounds__(256) void k_core_tiled(int n, Stencil st, int ncell
                                                     int min_pts, uint8_t* __restrict__ core,
                                                     int32_t* __restrict__ rest,
                                                     int32_t* __restrict__ rest_cnt,
+                                                    int* __restrict__ parent, int* __restrict__ min_orig,
+                                                    int32_t* __restrict__ flag /*[n + 1]*/,
                                                     unsigned long long* __restrict__ tests /*may be null:
                                                     [256] slots, candidates staged per wave (x 64 lanes
                                                     = lane-tests executed)*/) {
@@ -162,6 +164,14 @@ __global__ __launch_bounds__(256) void k_core_tiled(int n, Stencil st, int ncell
     core[p] = cnt >= min_pts;
     co.mark_core(p, cnt >= min_pts);
   }
+  // the start of the union phase rides along (it was a launch of its own, ~5 us): every point its own
+  // parent, no smallest index yet, no cluster flags
+  if (live) {
+    parent[p] = p;
+    min_orig[p] = 0x7F7F7F7F;  // > any index
+    flag[p] = 0;
+    if (p == n - 1) flag[n] = 0;
+  }
   if (tests && lane == 0) atomicAdd(tests + (blockIdx.x & 255), static_cast<unsigned long long>(staged));
 }
 
@@ -244,25 +254,6 @@ __device__ __forceinline__ void unite(int* parent, int a, int b) {
     // operations (atomics on one address are served one at a time).
     ra = find_root(parent, old);
     rb = find_root(parent, rb);
-  }
-}
-
-// Start of the union phase in one launch (it used to be a kernel and three memsets, ~4 us each):
-// every point its own parent, no smallest index yet, no cluster flags, empty lists.
-__global__ __launch_bounds__(256) void k_union_init(int n, int* __restrict__ parent,
-                                                    int* __restrict__ min_orig,
-                                                    int32_t* __restrict__ flag /*[n + 1]*/,
-                                                    int32_t* __restrict__ list_cnt /*[0], [2]*/) {
-  int p = blockIdx.x * 256 + threadIdx.x;
-  if (p < n) {
-    parent[p] = p;
-    min_orig[p] = 0x7F7F7F7F;  // > any index
-    flag[p] = 0;
-  }
-  if (p == 0) {
-    flag[n] = 0;
-    list_cnt[0] = 0;
-    list_cnt[2] = 0;
   }
 }
 
@@ -772,7 +763,7 @@ static int dbscan_device(Ctx* c, const double* xyz, int64_t n, double eps, int32
       ProfScope pk(c, "k_core_tiled");
       on_coords(g, [&](auto co) {
         hipLaunchKernelGGL(k_core_tiled<decltype(co)>, grid, block, 0, c->stream, N, st, int(g.ncell), g.start,
-                           g.cell_of, co, r2, min_pts, core, rest, list_cnt + 1, d_tests);
+                           g.cell_of, co, r2, min_pts, core, rest, list_cnt + 1, parent, min_orig, flag, d_tests);
       });
     }
     if (d_tests) {  // profiling level 2 only: read the counter back (synchronises)
@@ -791,7 +782,8 @@ static int dbscan_device(Ctx* c, const double* xyz, int64_t n, double eps, int32
   }
   {
     ProfScope ps(c, "dbscan_union");
-    hipLaunchKernelGGL(k_union_init, grid, block, 0, c->stream, N, parent, min_orig, flag, list_cnt);
+    // (parent / min_orig / flag were initialised by k_core_tiled; list_cnt[0] and [2] are still the zeros
+    // the binning left)
     if (fine) {
       hipLaunchKernelGGL(k_sub_rep, dim3(ceil_div(n, 1024)), dim3(1024), 0, c->stream, N, sub.sub_of, core,
                          g.order, parent, g.cell_of, sub.rec, run_min, list, list_cnt);

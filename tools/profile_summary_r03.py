@@ -145,18 +145,18 @@ out = {"points": 1_000_000,
        "note": "hbm_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 from separate rocprofv3 --pmc passes "
                f"(profiles/{ROUND}_*_pmc_*.csv): gfx950 FETCH_SIZE reports half the bytes read (MI355X_MICROARCH.md, "
                "HBM), calibrated on this code's own k_bbox (24 B per point read: FETCH_SIZE says 12); WRITE_SIZE is "
-               "exact (k_union_init: 12 B per point). launches_per_unit = dispatches seen / units of work in the pass; "
+               "exact (k_bk_scatter: one 32-byte record per point). launches_per_unit = dispatches seen / units of work in the pass; "
                "hbm_bytes_per_unit = sum over the kernels."}
 # the DBSCAN pass runs warmup + steps + one profiling-level-2 call = 7 clusterings
 k, tot = traffic("fetch", "write", 7, "dbscan", DB)
 out["dbscan"] = {"unit": "one clustering of the 1 M-point forest (dbscan step)", "units_in_pass": 7, "kernels": k,
                  "hbm_bytes_per_unit": tot}
-if "k_bbox" in k and "k_union_init" in k:
+if "k_bbox" in k and "k_bk_scatter" in k:
     out["calibration"] = {
         "k_bbox (reads the 24 B/point AoS cloud once)": {"actual_read_bytes": 24.0e6,
                                                          "FETCH_SIZE_bytes": k["k_bbox"]["fetch_size_kib"] * 1024},
-        "k_union_init (writes three int32 arrays of n)": {"actual_write_bytes": 12.0e6 + 4,
-                                                          "WRITE_SIZE_bytes": k["k_union_init"]["write_size_kib"] * 1024}}
+        "k_bk_scatter (writes one 32-byte record per point, block counters aside)": {
+            "actual_write_bytes": 32.0e6, "WRITE_SIZE_bytes": k["k_bk_scatter"]["write_size_kib"] * 1024}}
 lapj, solj = last_json(f"{SRC}/lap_fetch.json"), last_json(f"{SRC}/sol_fetch.json")
 if lapj:
     k, tot = traffic("lap_fetch", "lap_write", lapj["builds"], "laplacian", "python3 tools/prof_skel.py lap")
