@@ -65,6 +65,7 @@ static constexpr int kStragglers = 6;
 // tile can hold 5000 candidates (80 chunks) and a wave that cannot leave early was the tail
 // that set the kernel's duration (average wave 21 us, kernel 300 us).
 static constexpr int kMaxChunks = 6;
+static constexpr int kRestSegs = 64;  // segments (and counters) of the straggler list
 // centre, same-z rows, same-y rows, corners (compile-time: the run bounds stay in SGPRs)
 __device__ constexpr int kRunOrder[9] = {4, 3, 5, 1, 7, 0, 2, 6, 8};
 
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(256) void k_core_tiled(int n, Stencil st, int ncell
                                                     const int32_t* __restrict__ cell_of, CO co, double r2,
                                                     int min_pts, uint8_t* __restrict__ core,
                                                     int32_t* __restrict__ rest,
-                                                    int32_t* __restrict__ rest_cnt,
+                                                    int32_t* __restrict__ rest_cnt /*[kRestSegs]*/, int seg_cap,
                                                     int* __restrict__ parent, int* __restrict__ min_orig,
                                                     int32_t* __restrict__ flag /*[n + 1]*/,
                                                     unsigned long long* __restrict__ tests /*may be null:
@@ -147,10 +148,14 @@ __global__ __launch_bounds__(256) void k_core_tiled(int n, Stencil st, int ncell
           if (und != 0) {
             int slot = 0;
             const int lead = __ffsll(und) - 1;
-            if (lane == lead) slot = atomicAdd(rest_cnt, __popcll(und));
+            // kRestSegs counters, a block's stragglers go to segment blockIdx % kRestSegs of the list
+            // (capacity seg_cap: a block has at most 256): thousands of waves adding to ONE counter were
+            // served one at a time (~10 ns each), and every one of them waited for its turn
+            const int seg = blockIdx.x % kRestSegs;
+            if (lane == lead) slot = atomicAdd(rest_cnt + seg, __popcll(und));
             slot = __shfl(slot, lead, 64);
             if (live && cnt < min_pts) {
-              rest[slot + __popcll(und & ((1ull << lane) - 1ull))] = p;
+              rest[size_t(seg) * seg_cap + slot + __popcll(und & ((1ull << lane) - 1ull))] = p;
               cnt = -1;
             }
           }
@@ -180,14 +185,25 @@ __global__ __launch_bounds__(256) void k_core_tiled(int n, Stencil st, int ncell
 // ~850 candidates one dependent load at a time.)
 template <class CO>
 __global__ __launch_bounds__(256) void k_core_rest(const int32_t* __restrict__ rest,
-                                                   const int32_t* __restrict__ rest_cnt, Stencil st,
+                                                   const int32_t* __restrict__ rest_cnt /*[kRestSegs]*/,
+                                                   int seg_cap, Stencil st,
                                                    const int32_t* __restrict__ start,
                                                    const int32_t* __restrict__ cell_of, CO co, double r2,
                                                    int min_pts, uint8_t* __restrict__ core) {
-  const int m = *rest_cnt;
   const int lane = threadIdx.x & 63;
+  // the list is kRestSegs segments: lane s holds segment s's count, an inclusive scan numbers the entries
+  const int mine = rest_cnt[lane];
+  int incl = mine;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int v = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += v;
+  }
+  const int m = __shfl(incl, 63, 64);
   for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < m; i += gridDim.x * 4) {  // wave-uniform
-    const int p = rest[i];
+    const int seg = __popcll(__ballot(incl <= i));  // the first segment whose running total exceeds i
+    const int before = __shfl(incl - mine, seg, 64);
+    const int p = rest[size_t(seg) * seg_cap + (i - before)];
     double x, y, z;
     co.get(p, x, y, z);
     const int c = cell_of[p];
@@ -625,33 +641,34 @@ __global__ __launch_bounds__(256) void k_mark_roots(int n, const uint8_t* __rest
 // Labels of the core points; the others (noise and border candidates, a few percent) are
 // listed for k_labels_border. (Walking the stencil per lane here made those few points the
 // tail of the kernel: ~850 dependent gathers each.)
-__global__ __launch_bounds__(256) void k_labels(int n, const uint8_t* __restrict__ core,
-                                                const int* __restrict__ parent,
-                                                const int* __restrict__ min_orig,
-                                                const int32_t* __restrict__ rank,
-                                                const int32_t* __restrict__ order,
-                                                int64_t* __restrict__ labels,
-                                                uint8_t* __restrict__ is_core,
-                                                int32_t* __restrict__ rest,
-                                                int32_t* __restrict__ rest_cnt) {
-  int p = blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(1024) void k_labels(int n, const uint8_t* __restrict__ core,
+                                                 const int* __restrict__ parent,
+                                                 const int* __restrict__ min_orig,
+                                                 const int32_t* __restrict__ rank,
+                                                 const int32_t* __restrict__ order,
+                                                 int64_t* __restrict__ labels,
+                                                 uint8_t* __restrict__ is_core,
+                                                 int32_t* __restrict__ rest,
+                                                 int32_t* __restrict__ rest_cnt) {
+  int p = blockIdx.x * 1024 + threadIdx.x;
   const bool live = p < n;
   const bool is_c = live && core[p];
   if (is_c) labels[order[p]] = int64_t(rank[min_orig[parent[p]]]);
   if (live && is_core) is_core[order[p]] = is_c;
-  // block-aggregated append (one atomic per 256 threads)
-  __shared__ int wcount[4], wbase[4];
+  // block-aggregated append: one atomic per 1024 threads (atomics on one address are served one at a time)
+  __shared__ int wcount[16], wbase[16];
   const unsigned long long nb = __ballot(live && !is_c);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (lane == 0) wcount[w] = __popcll(nb);
   __syncthreads();
   if (threadIdx.x == 0) {
-    const int tot = wcount[0] + wcount[1] + wcount[2] + wcount[3];
-    const int base = tot ? atomicAdd(rest_cnt, tot) : 0;
-    wbase[0] = base;
-    wbase[1] = base + wcount[0];
-    wbase[2] = base + wcount[0] + wcount[1];
-    wbase[3] = base + wcount[0] + wcount[1] + wcount[2];
+    int tot = 0;
+    for (int k = 0; k < 16; ++k) tot += wcount[k];
+    int base = tot ? atomicAdd(rest_cnt, tot) : 0;
+    for (int k = 0; k < 16; ++k) {
+      wbase[k] = base;
+      base += wcount[k];
+    }
   }
   __syncthreads();
   if (live && !is_c) rest[wbase[w] + __popcll(nb & ((1ull << lane) - 1ull))] = p;
@@ -747,11 +764,16 @@ static int dbscan_device(Ctx* c, const double* xyz, int64_t n, double eps, int32
   if (sub.zeroed4) {
     list_cnt = sub.zeroed4;
   } else {
-    PQ_TRY(c->arena.get(4, &list_cnt));
-    PQ_HIP(hipMemsetAsync(list_cnt, 0, 16, c->stream));
+    PQ_TRY(c->arena.get(4 + kZeroedExtra, &list_cnt));
+    PQ_HIP(hipMemsetAsync(list_cnt, 0, (4 + kZeroedExtra) * 4, c->stream));
   }
   int32_t* rest;
-  PQ_TRY(c->arena.get(size_t(n), &rest));
+  // (the core pass's stragglers come in kRestSegs segments of seg_cap entries; the label pass reuses the
+  // array as one list of at most n)
+  const int core_blocks = int(ceil_div(n, 256));
+  const int seg_cap = ceil_div(core_blocks, kRestSegs) * 256;
+  PQ_TRY(c->arena.get(std::max<size_t>(size_t(n), size_t(seg_cap) * kRestSegs), &rest));
+  int32_t* const rest_segs = list_cnt + 4;  // kRestSegs zeroed counters
   {
     ProfScope ps(c, "dbscan_core");
     unsigned long long* d_tests = nullptr;
@@ -763,7 +785,7 @@ static int dbscan_device(Ctx* c, const double* xyz, int64_t n, double eps, int32
       ProfScope pk(c, "k_core_tiled");
       on_coords(g, [&](auto co) {
         hipLaunchKernelGGL(k_core_tiled<decltype(co)>, grid, block, 0, c->stream, N, st, int(g.ncell), g.start,
-                           g.cell_of, co, r2, min_pts, core, rest, list_cnt + 1, parent, min_orig, flag, d_tests);
+                           g.cell_of, co, r2, min_pts, core, rest, rest_segs, seg_cap, parent, min_orig, flag, d_tests);
       });
     }
     if (d_tests) {  // profiling level 2 only: read the counter back (synchronises)
@@ -776,7 +798,7 @@ static int dbscan_device(Ctx* c, const double* xyz, int64_t n, double eps, int32
     }
     on_coords(g, [&](auto co) {
       hipLaunchKernelGGL(k_core_rest<decltype(co)>, dim3(std::min<int64_t>(8192, ceil_div(n, 64))), block, 0,
-                         c->stream, rest, list_cnt + 1, st, g.start, g.cell_of, co, r2, min_pts, core);
+                         c->stream, rest, rest_segs, seg_cap, st, g.start, g.cell_of, co, r2, min_pts, core);
     });
     PQ_HIP(hipGetLastError());
   }
@@ -881,7 +903,7 @@ static int dbscan_device(Ctx* c, const double* xyz, int64_t n, double eps, int32
   }
   {
     ProfScope ps(c, "dbscan_label");
-    hipLaunchKernelGGL(k_labels, grid, block, 0, c->stream, N, core, parent, min_orig, flag, g.order,
+    hipLaunchKernelGGL(k_labels, dim3(ceil_div(n, 1024)), dim3(1024), 0, c->stream, N, core, parent, min_orig, flag, g.order,
                        labels, is_core, rest, list_cnt + 3);
     on_coords(g, [&](auto co) {
       hipLaunchKernelGGL(k_labels_border<decltype(co)>, dim3(std::min<int64_t>(8192, ceil_div(n, 64))), block, 0,

@@ -1293,9 +1293,9 @@ int build_grid_octants(Ctx* c, const double* xyz, int64_t n, double min_cell, in
   // bounding box's fold kernel on its way (two memset launches less)
   // layout: [kBkMax totals | kBkMax reservation cursors | big-cell counter | four spare zeros for the caller]
   int32_t* tot_big = nullptr;
-  PQ_TRY(c->arena.get(size_t(2 * kBkMax) + 5, &tot_big));
+  PQ_TRY(c->arena.get(size_t(2 * kBkMax) + 5 + kZeroedExtra, &tot_big));
   bool all_f32 = false;
-  PQ_TRY(cloud_bbox(c, xyz, n, mn, mx, &all_f32, tot_big, 2 * kBkMax + 5));
+  PQ_TRY(cloud_bbox(c, xyz, n, mn, mx, &all_f32, tot_big, 2 * kBkMax + 5 + kZeroedExtra));
   sub->zeroed4 = tot_big + 2 * kBkMax + 1;
   {
     const char* f32_env = getenv("PYQSM_COORD_F32");  // "0": keep fp64 storage (A/B comparisons)

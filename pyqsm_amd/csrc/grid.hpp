@@ -203,8 +203,10 @@ struct SubCells {
   int4* rec;         // [8 n] (sub_beg, sub_cnt, -1, 0) in one 16-byte record; .z is the caller's
   // build_grid_octants only: four ints the binning's own kernels left zeroed, for the caller's
   // counters (spares DBSCAN two memset launches per step); nullptr from subsort_octants
+  // (+ kZeroedExtra more zeroed ints behind the four: DBSCAN's segmented list counters)
   int32_t* zeroed4 = nullptr;
 };
+static constexpr int kZeroedExtra = 64;
 
 // Re-sorts g's point arrays in place (order, sx, sy, sz are replaced by new arena arrays;
 // start and cell_of stay valid: the permutation is within cells).
