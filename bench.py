@@ -628,7 +628,7 @@ def main():
         rec, _ = c5.run(scale=1.0, skeleton_iters=20, max_trees=100, engine="native")
         out["config5"] = {
             "workload": "5 M-point scan (100 trees) -> DBSCAN -> 100 x extract_skeleton (20 contractions, "
-                        "block-diagonal batches of 600 k points) -> RANSAC circles on every 0.5 m stem slice "
+                        "block-diagonal batches of 1 M points, six host threads) -> RANSAC circles on every 0.5 m stem slice "
                         "(H = 1000) -> 50 M sun rays (5 angles x 10 M) x 500 k triangles; one MI355X, host "
                         "buffers in and out at every stage (PCIe included)",
             "stage_s": {k: rec[k] for k in ("dbscan_s", "skeleton_s", "ransac_s", "rays_s")},

@@ -32,8 +32,8 @@ from pyqsm_amd.set_config import config  # noqa: E402
 from pyqsm_amd.viz.ray_casting import cast_rays  # noqa: E402
 
 
-def run(scale=0.04, skeleton_iters=3, max_trees=2, workers=8, gpus=1, engine="python", batch_workers=4,
-        ransac_batch=1, group_points=600_000, keep=False):
+def run(scale=0.04, skeleton_iters=3, max_trees=2, workers=8, gpus=1, engine="python", batch_workers=6,
+        ransac_batch=1, group_points=1_000_000, keep=False):
     """The pipeline; returns the JSON-able record of stage times and, with ``keep``, a second dict
     holding what the stages produced (cluster index lists, per-tree contraction results, per-tree
     slice fits with their samples, per-angle hit arrays) for tests to check."""
@@ -169,10 +169,10 @@ def main():
                                                         "PYQSM_MULTI_FAKE_RANKS=N: logical GPUs on one device)")
     ap.add_argument("--engine", default="python", help="contraction loop of a group: python or native "
                                                          "(pyqsm_extract_skeleton, segments in HBM)")
-    ap.add_argument("--batch-workers", type=int, default=4, help="host threads contracting groups")
+    ap.add_argument("--batch-workers", type=int, default=6, help="host threads contracting groups")
     ap.add_argument("--ransac-batch", type=int, default=1,
                     help="1: all z-slices of a tree in one pyqsm_ransac_batch call; 0: a call per slice")
-    ap.add_argument("--group-points", type=int, default=600_000,
+    ap.add_argument("--group-points", type=int, default=1_000_000,
                     help="trees are contracted in block-diagonal groups of up to this many points "
                          "(extract_skeleton_batch); 0 = one extract_skeleton call per tree")
     args = ap.parse_args()
