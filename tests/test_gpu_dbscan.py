@@ -111,6 +111,21 @@ def test_sizes_around_a_wave(gpu, n):
     _check(rng.normal(0, 0.05, (n, 3)), 0.03, 3, gpu)
 
 
+@pytest.mark.parametrize("n", [70_001, 300_000])
+def test_every_point_a_straggler_of_the_core_pass(gpu, n):
+    """A sparse uniform cloud (a neighbour or two within eps, min_pts = 10): no lane of the tiled core pass
+    ever reaches min_pts, so every wave hands all of its 64 points to the straggler list — whose 64
+    segments (one counter each, dbscan.hip: kRestSegs) are then filled to their capacity of 256 points per
+    block — and k_core_rest recounts every point of the cloud. Labels against the oracle: all noise but
+    the few chance clusters."""
+    rng = np.random.default_rng(n)
+    side = (n / 2.0) ** (1.0 / 3.0) * 0.05
+    P = rng.uniform(0.0, side, (n, 3))
+    _check(P, 0.03, 10, gpu)
+    lab, core = hip.dbscan(P, 0.03, 10, device=gpu)
+    assert (lab == -1).mean() > 0.9
+
+
 def test_planar_and_single_cell(gpu):
     rng = np.random.default_rng(9)
     P = np.concatenate([rng.uniform(0, 1, (8000, 2)), np.zeros((8000, 1))], 1)
