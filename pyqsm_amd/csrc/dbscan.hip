@@ -506,7 +506,22 @@ __global__ __launch_bounds__(256) void k_union_sub(const int4* __restrict__ list
   for (int u = 0; u < kSubPerWave; ++u) {
     const int p = me[u].x, n1 = me[u].w;
     bool need = rep2[u] >= 0 && !(a1[u] == a2[u] || a2[u] == p || a1[u] == rep2[u]);
-    if (need) need = find_root(parent, rep2[u]) != find_root(parent, p);
+    int root2 = -1;  // the neighbour's tree, as the coherent look found it
+    if (need) {
+      // The coherent look: both chains at once, starting from the ancestors the plain reads named (after
+      // the compression those are the roots unless this launch has hooked them since) — four dependent
+      // agent-scope loads per doubtful pair became one or two. (Without this step the pass takes 21 us:
+      // its table and the quick test; the doubtful pairs were the other 44.)
+      int ra = a1[u], rb = a2[u];
+      for (;;) {
+        const int pa = ld_parent(parent, ra), pb = ld_parent(parent, rb);
+        if (pa == ra && pb == rb) break;
+        ra = pa;
+        rb = pb;
+      }
+      need = ra != rb;
+      root2 = rb;
+    }
     unsigned long long todo = __ballot(need);
     if (!todo) continue;
     int q0 = 0, n2 = 0;
@@ -519,6 +534,7 @@ __global__ __launch_bounds__(256) void k_union_sub(const int4* __restrict__ list
       const int src = __ffsll(todo) - 1;
       todo &= todo - 1;
       const int qb = __shfl(q0, src, 64), nb = __shfl(n2, src, 64), rb = __shfl(rep2[u], src, 64);
+      const int tree = __shfl(root2, src, 64);
       const int pairs = n1 * nb;
       bool found = false;
       for (int base = 0; base < pairs && !found; base += 64) {
@@ -530,7 +546,13 @@ __global__ __launch_bounds__(256) void k_union_sub(const int4* __restrict__ list
         }
         found = __ballot(hit) != 0;
       }
-      if (found && k == 0) unite(parent, p, rb);
+      if (found) {
+        if (k == 0) unite(parent, p, rb);
+        // this sub-cell now hangs together with that whole tree: its other doubtful neighbours in the same
+        // tree need no test and no union (a sub-cell on the seam of two trees has ~7 of them, and a wave
+        // went through them one after the other — test, two coherent finds, a CAS on the same hot root)
+        todo &= ~__ballot(root2 == tree);
+      }
     }
   }
   }
