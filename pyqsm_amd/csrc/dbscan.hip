@@ -459,9 +459,11 @@ __global__ __launch_bounds__(256) void k_hook_sub(const int4* __restrict__ list,
       if (found && k == 0) parent[p] = parent[rb];
     }
   }
-  // (Taking the wave's sub-cells in rounds — one candidate of each per round, their gathers issued
-  // side by side, idle lanes reading the sub-cell's own representative — was SLOWER, 104 against 82 us
-  // per million points: the depth of one wave's dependent chain is not what bounds the pass.)
+  // (Taking the wave's sub-cells in rounds — one candidate of each per round, the records of all of them
+  // loaded before the first verdict — was SLOWER both times it was built: 104 us with idle lanes loading a
+  // dummy record, 112 us with predicated loads and finished sub-cells skipped, against 81. The look-ups
+  // above are 48 of those 81 us and live on occupancy (half the resident waves: 118 us); the rounds'
+  // record arrays cost the registers that occupancy needs.)
   }
 }
 
