@@ -449,14 +449,15 @@ __global__ __launch_bounds__(256) void k_hook_sub(const int4* __restrict__ list,
       const int src = __ffsll(todo) - 1;
       todo &= todo - 1;
       const int qb = __shfl(q0[u], src, 64), nb = __shfl(n2[u], src, 64), rb = __shfl(rep2[u], src, 64);
-      const int pairs = n1 * nb;
+      // pair (i, j) of the two runs sits at index (i << sh) | j, sh = bits of nb - 1: no division by a
+      // run length per lane and step (~40 instructions), at the price of idle lanes where nb is no power of two
+      const int sh = nb > 1 ? 32 - __clz(nb - 1) : 0;
+      const int pairs = n1 << sh;
       for (int base = 0; base < pairs && !found; base += 64) {
         const int idx = base + k;
+        const int j = idx & ((1 << sh) - 1);
         bool hit = false;
-        if (idx < pairs) {
-          const int a = p + idx / nb, q = qb + idx % nb;
-          hit = co.core_pair_within(a, q, core, r2);
-        }
+        if (idx < pairs && j < nb) hit = co.core_pair_within(p + (idx >> sh), qb + j, core, r2);
         found = __ballot(hit) != 0;
       }
       // Hang under the neighbour's own pointer rather than under the neighbour: sub-cells are
@@ -548,15 +549,14 @@ __global__ __launch_bounds__(256) void k_union_sub(const int4* __restrict__ list
       todo &= todo - 1;
       const int qb = __shfl(q0, src, 64), nb = __shfl(n2, src, 64), rb = __shfl(rep2[u], src, 64);
       const int tree = __shfl(root2, src, 64);
-      const int pairs = n1 * nb;
+      const int sh = nb > 1 ? 32 - __clz(nb - 1) : 0;  // (as in k_hook_sub: shift and mask, no division)
+      const int pairs = n1 << sh;
       bool found = false;
       for (int base = 0; base < pairs && !found; base += 64) {
         const int idx = base + k;
+        const int j = idx & ((1 << sh) - 1);
         bool hit = false;
-        if (idx < pairs) {
-          const int a = p + idx / nb, q = qb + idx % nb;
-          hit = co.core_pair_within(a, q, core, r2);
-        }
+        if (idx < pairs && j < nb) hit = co.core_pair_within(p + (idx >> sh), qb + j, core, r2);
         found = __ballot(hit) != 0;
       }
       if (found) {
