@@ -180,6 +180,37 @@ __global__ __launch_bounds__(256) void k_core_tiled(int n, Stencil st, int ncell
   if (tests && lane == 0) atomicAdd(tests + (blockIdx.x & 255), static_cast<unsigned long long>(staged));
 }
 
+// The 27-cell stencil of one point as ONE sequence of candidates: the nine runs' bounds are loaded side
+// by side (they used to be fetched row by row, a dependent round trip each before the row's candidates
+// could be asked for), and candidate g of the sequence is found by a chain of selects. Wave-uniform.
+struct Runs9 {
+  int qb[9];
+  int pre[10];  // pre[r] = candidates before run r, pre[9] = all
+  __device__ __forceinline__ int at(int g) const {  // sorted position of candidate g < pre[9]
+    int q = qb[0] + g;
+#pragma unroll
+    for (int r = 1; r < 9; ++r) q = g >= pre[r] ? qb[r] + (g - pre[r]) : q;
+    return q;
+  }
+};
+__device__ __forceinline__ Runs9 stencil_runs(int c, Stencil st, const int32_t* __restrict__ start) {
+  Runs9 t;
+  int qe[9];
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {
+    const int row = c + (r % 3 - 1) * st.nx + (r / 3 - 1) * st.nxy;
+    t.qb[r] = start[row - 1];
+    qe[r] = start[row + 2];
+  }
+  t.pre[0] = 0;
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {
+    t.qb[r] = __builtin_amdgcn_readfirstlane(t.qb[r]);
+    t.pre[r + 1] = t.pre[r] + (__builtin_amdgcn_readfirstlane(qe[r]) - t.qb[r]);
+  }
+  return t;
+}
+
 // The stragglers of k_core_tiled, one WAVE each: 64 candidates of the stencil per step,
 // stop at min_pts. (One lane each was 0.13 ms per million points: a noise point walks
 // ~850 candidates one dependent load at a time.)
@@ -206,18 +237,14 @@ __global__ __launch_bounds__(256) void k_core_rest(const int32_t* __restrict__ r
     const int p = rest[size_t(seg) * seg_cap + (i - before)];
     double x, y, z;
     co.get(p, x, y, z);
-    const int c = cell_of[p];
+    const int c = __builtin_amdgcn_readfirstlane(cell_of[p]);
+    const Runs9 t = stencil_runs(c, st, start);
     int cnt = 0;
-    for (int dz = -1; dz <= 1 && cnt < min_pts; ++dz)
-      for (int dy = -1; dy <= 1 && cnt < min_pts; ++dy) {
-        const int row = c + dy * st.nx + dz * st.nxy;
-        const int qe = start[row + 2];
-        for (int base = start[row - 1]; base < qe && cnt < min_pts; base += 64) {
-          const int q = base + lane;
-          const bool hit = q < qe && co.d2(q, x, y, z) <= r2;
-          cnt += __popcll(__ballot(hit));
-        }
-      }
+    for (int g0 = 0; g0 < t.pre[9] && cnt < min_pts; g0 += 64) {
+      const int g = g0 + lane;
+      const bool hit = g < t.pre[9] && co.d2(t.at(g), x, y, z) <= r2;
+      cnt += __popcll(__ballot(hit));
+    }
     if (lane == 0) {
       core[p] = cnt >= min_pts;
       co.mark_core(p, cnt >= min_pts);
@@ -727,20 +754,19 @@ __global__ __launch_bounds__(256) void k_labels_border(const int32_t* __restrict
     const int p = rest[i];
     double x, y, z;
     co.get(p, x, y, z);
-    const int c = cell_of[p];
+    const int c = __builtin_amdgcn_readfirstlane(cell_of[p]);
+    const Runs9 t = stencil_runs(c, st, start);
     int best = kNoRoot;
-    for (int dz = -1; dz <= 1; ++dz)
-      for (int dy = -1; dy <= 1; ++dy) {
-        const int row = c + dy * st.nx + dz * st.nxy;
-        const int qe = start[row + 2];
-        for (int base = start[row - 1]; base < qe; base += 64) {
-          const int q = base + lane;
-          if (q < qe && core[q] && co.d2(q, x, y, z) <= r2) {
-            const int mo = min_orig[parent[q]];
-            best = mo < best ? mo : best;
-          }
+    for (int g0 = 0; g0 < t.pre[9]; g0 += 64) {
+      const int g = g0 + lane;
+      if (g < t.pre[9]) {
+        const int q = t.at(g);
+        if (core[q] && co.d2(q, x, y, z) <= r2) {
+          const int mo = min_orig[parent[q]];
+          best = mo < best ? mo : best;
         }
       }
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
       const int o = __shfl_xor(best, off, 64);
