@@ -33,7 +33,7 @@ from pyqsm_amd.viz.ray_casting import cast_rays  # noqa: E402
 
 
 def run(scale=0.04, skeleton_iters=3, max_trees=2, workers=8, gpus=1, engine="python", batch_workers=6,
-        ransac_batch=1, group_points=1_000_000, keep=False):
+        ransac_batch=2, group_points=1_000_000, keep=False):
     """The pipeline; returns the JSON-able record of stage times and, with ``keep``, a second dict
     holding what the stages produced (cluster index lists, per-tree contraction results, per-tree
     slice fits with their samples, per-angle hit arrays) for tests to check."""
@@ -117,7 +117,9 @@ def run(scale=0.04, skeleton_iters=3, max_trees=2, workers=8, gpus=1, engine="py
         smp = [draw_samples(len(sl), 1000, seed=st) for sl, st in zip(slices, streams)]
         tc = time.perf_counter()
         stage_t["draw"] += tc - tb
-        if ransac_batch:                                    # all slices of the tree in one call
+        if ransac_batch >= 2:                               # fitted below, all trees of a GPU in one call
+            fits = None
+        elif ransac_batch:                                  # all slices of the tree in one call
             fits = fit_shape_RANSAC_batch(slices, shape="circle", threshold=0.04, max_radius=0.3 * 1.75,
                                           samples=smp, device=phys[k % n_gpus])
         else:
@@ -128,6 +130,29 @@ def run(scale=0.04, skeleton_iters=3, max_trees=2, workers=8, gpus=1, engine="py
 
     with ThreadPoolExecutor(max_workers=max(1, workers) * n_gpus) as pool:
         per_tree = list(pool.map(fit_slices, enumerate(idxs[: max(max_trees, 4)])))
+    if ransac_batch >= 2:
+        # ONE pyqsm_ransac_batch call per GPU over every slice of its trees (a call per tree was a hundred
+        # calls from eight threads, 0.15 s on a good box and 1.2 s on one whose host was busy)
+        tc = time.perf_counter()
+
+        def fit_device(d):
+            mine = [k for k in range(len(per_tree)) if k % n_gpus == d and per_tree[k][1]]
+            if not mine:
+                return
+            flat = [sl for k in mine for sl in per_tree[k][1]]
+            smps = [q for k in mine for q in per_tree[k][2]]
+            fits = fit_shape_RANSAC_batch(flat, shape="circle", threshold=0.04, max_radius=0.3 * 1.75,
+                                          samples=smps, device=phys[d])
+            at = 0
+            for k in mine:
+                m = len(per_tree[k][1])
+                per_tree[k] = (fits[at:at + m], per_tree[k][1], per_tree[k][2])
+                at += m
+
+        with ThreadPoolExecutor(max_workers=n_gpus) as pool:
+            list(pool.map(fit_device, range(n_gpus)))
+        per_tree = [(f if f is not None else [], sl, q) for f, sl, q in per_tree]
+        stage_t["fit"] += time.perf_counter() - tc
     radii = [float(f[3]) for fits, _, _ in per_tree for f in fits if f[0] is not None]
     out["ransac_s"] = time.perf_counter() - t0
     out["ransac_thread_seconds"] = {k: round(v, 3) for k, v in stage_t.items()}
@@ -170,8 +195,9 @@ def main():
     ap.add_argument("--engine", default="python", help="contraction loop of a group: python or native "
                                                          "(pyqsm_extract_skeleton, segments in HBM)")
     ap.add_argument("--batch-workers", type=int, default=6, help="host threads contracting groups")
-    ap.add_argument("--ransac-batch", type=int, default=1,
-                    help="1: all z-slices of a tree in one pyqsm_ransac_batch call; 0: a call per slice")
+    ap.add_argument("--ransac-batch", type=int, default=2,
+                    help="2: every slice of every tree of a GPU in one pyqsm_ransac_batch call; 1: a call per tree; "
+                         "0: a call per slice")
     ap.add_argument("--group-points", type=int, default=1_000_000,
                     help="trees are contracted in block-diagonal groups of up to this many points "
                          "(extract_skeleton_batch); 0 = one extract_skeleton call per tree")
