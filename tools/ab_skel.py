@@ -20,6 +20,8 @@ for rep in range(2):
     lap = sum(hip.prof_get(k)[0] for k in ("lap_knn", "lap_fans", "lap_assemble"))
     flips = hip.prof_get("lap_flips")[0]
     hip.prof_enable(False)
-    print(f"n={n} c={c}: {dt:.3f} s, multigrid-CG iterations {it[1]} in {it[0]:.0f} ms ({it[0]/max(it[1],1)*1e3:.1f} us each), "
+    bad = sum(1 for q in got.solve_log if not q["ok"])
+    fin = bool(np.isfinite(total).all() and np.isfinite(got.points).all())
+    print(f"n={n} c={c}: {dt:.3f} s, not-ok solves {bad}, finite {fin}, multigrid-CG iterations {it[1]} in {it[0]:.0f} ms ({it[0]/max(it[1],1)*1e3:.1f} us each), "
           f"Laplacian builds {lap:.0f} ms (flips {flips:.0f}), sha {hashlib.sha1(total.tobytes()).hexdigest()[:12]} env "
           + " ".join(f"{k[6:]}={v}" for k, v in os.environ.items() if k.startswith("PYQSM_")), flush=True)
