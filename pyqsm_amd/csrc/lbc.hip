@@ -598,6 +598,14 @@ static int amg_fixed_iterations() {
 
 static constexpr int kAmgFirstBurst = 8;  // a 1e-2 solve takes 10-14 iterations: no look before 8
 static constexpr int kAmgBurst = 2;       // then a residual check every 2
+static int amg_next_burst() {  // PYQSM_AMG_BURST: iterations between two looks after the first (even, 2-16)
+  static const int v = [] {
+    const char* e = getenv("PYQSM_AMG_BURST");
+    const int b = e ? atoi(e) : kAmgBurst;
+    return b >= 2 && b <= 16 ? (b & ~1) : kAmgBurst;
+  }();
+  return v;
+}
 static int amg_first_burst() {
   static const int v = [] {
     const char* e = getenv("PYQSM_AMG_FIRST_BURST");
@@ -663,7 +671,7 @@ static int amg_pcg(Ctx* c, const System& S, const Work& w, AmgHierarchy* H, cons
   int it = 0;
   bool done = false;
   while (!done && it < max_it) {
-    int len = it == 0 ? amg_first_burst() : kAmgBurst;
+    int len = it == 0 ? amg_first_burst() : amg_next_burst();
     if (len > max_it - it) len = std::max(2, (max_it - it + 1) & ~1);  // even: bursts start at parity 0
     {
       ProfScope ps(c, "lbc_amg_iter", len);
@@ -910,7 +918,7 @@ static int amg_pcg_f32(Ctx* c, int N, const WorkF& w, AmgHierarchy* H, const flo
     return 0;
   }
   while (!done && it < max_it) {
-    int len = it == 0 ? amg_first_burst() : kAmgBurst;
+    int len = it == 0 ? amg_first_burst() : amg_next_burst();
     if (len > max_it - it) len = std::max(2, (max_it - it + 1) & ~1);
     {
       ProfScope ps(c, "lbc_amg_iter", len);
