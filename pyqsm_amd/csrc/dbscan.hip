@@ -63,8 +63,10 @@ struct TileLds {
 static constexpr int kStragglers = 6;
 // ... and after kMaxChunks chunks everybody still short goes there, whatever their number: a
 // tile can hold 5000 candidates (80 chunks) and a wave that cannot leave early was the tail
-// that set the kernel's duration (average wave 21 us, kernel 300 us).
-static constexpr int kMaxChunks = 6;
+// that set the kernel's duration (average wave 21 us, kernel 300 us). (6 until the end of round 3; with
+// k_core_rest taking a point's stencil as one sequence the balance moved: 10 / 6 / 4 / 3 / 2 / 1 chunks ->
+// core phase 0.104 / 0.091 / 0.083 / 0.079 / 0.079 / 0.188 ms per million points at min_pts = 10.)
+static constexpr int kMaxChunks = 3;  // for min_pts <= 10; more neighbours asked for, more chunks (core_max_chunks)
 static constexpr int kRestSegs = 64;  // segments (and counters) of the straggler list
 // centre, same-z rows, same-y rows, corners (compile-time: the run bounds stay in SGPRs)
 __device__ constexpr int kRunOrder[9] = {4, 3, 5, 1, 7, 0, 2, 6, 8};
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(256) void k_core_tiled(int n, Stencil st, int ncell
                                                     int32_t* __restrict__ rest,
                                                     int32_t* __restrict__ rest_cnt /*[kRestSegs]*/, int seg_cap,
                                                     int* __restrict__ parent, int* __restrict__ min_orig,
-                                                    int32_t* __restrict__ flag /*[n + 1]*/,
+                                                    int32_t* __restrict__ flag /*[n + 1]*/, int max_chunks,
                                                     unsigned long long* __restrict__ tests /*may be null:
                                                     [256] slots, candidates staged per wave (x 64 lanes
                                                     = lane-tests executed)*/) {
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(256) void k_core_tiled(int n, Stencil st, int ncell
         __builtin_amdgcn_wave_barrier();
         const unsigned long long und = __ballot(live && cnt < min_pts);
         ++chunks;
-        if ((__popcll(und) <= kStragglers || chunks >= kMaxChunks) &&
+        if ((__popcll(und) <= kStragglers || chunks >= max_chunks) &&
             !(ri == 8 && base + 64 >= t.qe[r])) {
           // the few lanes still short restart on their own in k_core_rest
           if (und != 0) {
@@ -844,11 +846,14 @@ static int dbscan_device(Ctx* c, const double* xyz, int64_t n, double eps, int32
       PQ_TRY(c->arena.get(256, &d_tests));
       PQ_HIP(hipMemsetAsync(d_tests, 0, 256 * 8, c->stream));
     }
+    // chunks of 64 candidates a wave of the tiled pass looks at before it hands its short lanes on: three
+    // serve min_pts = 10, and in proportion beyond
+    const int max_chunks = std::min(32, std::max(kMaxChunks, (kMaxChunks * min_pts + 9) / 10));
     {
       ProfScope pk(c, "k_core_tiled");
       on_coords(g, [&](auto co) {
         hipLaunchKernelGGL(k_core_tiled<decltype(co)>, grid, block, 0, c->stream, N, st, int(g.ncell), g.start,
-                           g.cell_of, co, r2, min_pts, core, rest, rest_segs, seg_cap, parent, min_orig, flag, d_tests);
+                           g.cell_of, co, r2, min_pts, core, rest, rest_segs, seg_cap, parent, min_orig, flag, max_chunks, d_tests);
       });
     }
     if (d_tests) {  // profiling level 2 only: read the counter back (synchronises)
