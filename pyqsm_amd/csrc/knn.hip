@@ -143,7 +143,7 @@ __global__ __launch_bounds__(T) void k_knn(int n_query, const int32_t* __restric
   }
   for (int j = 0; j < k; ++j) {
     out_idx[size_t(self) * k + j] = j < have ? bi[j * T + t] : n_total;
-    out_d2[size_t(self) * k + j] = j < have ? bd[j * T + t] : __builtin_inf();
+    if (out_d2) out_d2[size_t(self) * k + j] = j < have ? bd[j * T + t] : __builtin_inf();
   }
 }
 
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256) void k_knn_reg(int n_query, KnnGrid g,
     if (j < k) {
       const bool have = bd[j] < __builtin_inf();
       out_idx[size_t(self) * k + j] = have ? bi[j] : n_total;
-      out_d2[size_t(self) * k + j] = bd[j];
+      if (out_d2) out_d2[size_t(self) * k + j] = bd[j];
     }
 }
 
@@ -598,7 +598,7 @@ __global__ __launch_bounds__(256) void k_knn_wave(int n_query,
   }
   if (lane < k) {
     out_idx[size_t(self) * k + lane] = lane < have ? bi : n_total;
-    out_d2[size_t(self) * k + lane] = lane < have ? bd : __builtin_inf();
+    if (out_d2) out_d2[size_t(self) * k + lane] = lane < have ? bd : __builtin_inf();
   }
   }
 }
@@ -750,7 +750,7 @@ __global__ __launch_bounds__(256) void k_knn_brute_merge(int n_query, const int3
   }
   if (lane < k) {
     out_idx[size_t(self) * k + lane] = lane < have ? bi : n;
-    out_d2[size_t(self) * k + lane] = lane < have ? bd : __builtin_inf();
+    if (out_d2) out_d2[size_t(self) * k + lane] = lane < have ? bd : __builtin_inf();
   }
 }
 

@@ -1205,9 +1205,10 @@ int laplacian_device(Ctx* c, const double* d_xyz, int64_t n, const int64_t* seg_
                      int32_t k, double moll, LapOut* out) {
   const int N = int(n);
   int32_t* d_nbr;
-  double* d_d2;
   PQ_TRY(c->arena.get(size_t(n) * k, &d_nbr));
-  PQ_TRY(c->arena.get(size_t(n) * k, &d_d2));
+  // (the build uses the neighbours' indices only: no distances are asked for — 160 MB per million points
+  // that the search kernels would write, a row of 160 bytes per lane)
+  double* const d_d2 = nullptr;
   {
     ProfScope ps(c, "lap_knn");
     PQ_TRY(knn_device(c, d_xyz, n, k, 1, d_nbr, d_d2));
